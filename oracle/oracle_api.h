@@ -1,0 +1,63 @@
+/*
+ * oracle_api.h -- plain-C scene description and result records shared by the two CPU checkers.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the shipped engine: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load these libraries, and only as the
+ * checker.  The product path (trajopt_amd/, include/) never links or imports them.
+ *
+ *   oracle/trajopt_oracle.c   -> oracle/liboracle.so      CPU restatement (travels to the GPU box)
+ *   oracle/ref_driver.cpp     -> oracle/_ref/libref.so    the reference's own vendored Bullet, compiled from
+ *                                                         /root/reference in the build container only
+ *
+ * The scene format is "what OpenRAVE would hand to BulletCollisionChecker", flattened:
+ *   shape   = one convex geometry (reference: createShapePrimitive, bullet_collision_checker.cpp:134-212)
+ *   child   = one geometry of a link: a shape + its local transform (geom->GetTransform())
+ *   object  = one link with geometry = one Bullet collision object (CollisionObjectFromLink, :215-255)
+ * Transforms are OpenRAVE style: 7 doubles (qw qx qy qz tx ty tz); the checkers round them to fp32 exactly
+ * as toBt() does (bullet_collision_checker.cpp:72-83).
+ */
+#ifndef TRAJOPT_ORACLE_API_H
+#define TRAJOPT_ORACLE_API_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORA_BOX = 0, ORA_HULL = 1, ORA_SPHERE = 2, ORA_CYLZ = 3 };
+enum { ORA_GROUP_ROBOT = 1, ORA_GROUP_KINBODY = 2 }; /* collision_checker.hpp:32-35 */
+enum { ORA_CC_NONE = 0, ORA_CC_TIME0 = 1, ORA_CC_TIME1 = 2, ORA_CC_BETWEEN = 3 }; /* collision_checker.hpp:12-17 */
+
+typedef struct ora_scene {
+  int n_shapes;
+  const int *shape_kind;     /* [n_shapes] ORA_*                                            */
+  const float *shape_param;  /* [n_shapes*4] box: half extents xyz; sphere: r; cylZ: r, h/2 */
+  const int *shape_voff;     /* [n_shapes] first vertex (hulls)                             */
+  const int *shape_vcnt;     /* [n_shapes] vertex count (hulls, <= 64)                      */
+  int n_verts;
+  const float *verts;        /* [n_verts*3] xyz, fp32, exactly the points given to addPoint */
+  int n_children;
+  const int *child_shape;    /* [n_children]                                                */
+  const double *child_T;     /* [n_children*7] local transform of the geometry in its link  */
+  int n_objects;
+  const int *obj_child_off;  /* [n_objects]                                                 */
+  const int *obj_child_cnt;  /* [n_objects]                                                 */
+  const int *obj_compound;   /* [n_objects] 0: bare convex shape (one geom at identity), 1: btCompoundShape */
+  const int *obj_group;      /* [n_objects] ORA_GROUP_*                                     */
+} ora_scene;
+
+/* One contact, in the reference's Collision layout (collision_checker.hpp:19-29) with links replaced by
+ * (object, child) ids.  A/B follow Bullet's GJK roles (cast contacts: after the collector's swap, B is
+ * the swept robot link). */
+typedef struct ora_contact {
+  int objA, childA, objB, childB;
+  int cctype;
+  float time;
+  double dist;
+  double n[3];   /* normalB2A */
+  double ptA[3], ptB[3], ptB1[3];
+} ora_contact;
+
+#ifdef __cplusplus
+}
+#endif
+#endif
