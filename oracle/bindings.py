@@ -3,7 +3,8 @@
 Importers allowed: tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
   * ``load_oracle()`` -> oracle/liboracle.so   (CPU restatement; built by ``make -C oracle oracle``)
   * ``load_ref()``    -> oracle/_ref/libref.so (reference's vendored Bullet; only where it was built)
-Both expose the same world API over the flat ``ora_scene`` of oracle_api.h.
+Both expose the same world API over the flat ``ora_scene`` of oracle_api.h; scenes and robots are described with
+trajopt_amd.model.Scene / RobotModel (plain numpy arrays).
 """
 import ctypes as C
 import os
@@ -11,11 +12,6 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-
-BOX, HULL, SPHERE, CYLZ = 0, 1, 2, 3
-GROUP_ROBOT, GROUP_KINBODY = 1, 2
-CC_NONE, CC_TIME0, CC_TIME1, CC_BETWEEN = 0, 1, 2, 3
-IDENT7 = (1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
 
 
 class OraScene(C.Structure):
@@ -37,100 +33,65 @@ class OraContact(C.Structure):
     ]
 
 
+class OraRobot(C.Structure):
+    _fields_ = [
+        ("n_links", C.c_int), ("parent", C.POINTER(C.c_int)), ("jtype", C.POINTER(C.c_int)),
+        ("T_origin", C.POINTER(C.c_double)), ("axis", C.POINTER(C.c_double)), ("dof", C.POINTER(C.c_int)),
+        ("mult", C.POINTER(C.c_double)), ("offs", C.POINTER(C.c_double)), ("link_obj", C.POINTER(C.c_int)),
+        ("n_dof", C.c_int), ("q_robot", C.POINTER(C.c_double)), ("base_T", C.c_double * 7),
+        ("n_joint_inds", C.c_int), ("joint_inds", C.POINTER(C.c_int)), ("affine", C.c_int),
+        ("rot_axis", C.c_double * 3),
+    ]
+
+
+class OraLin(C.Structure):
+    _fields_ = [("t", C.c_int), ("c", OraContact), ("const0", C.c_double), ("const1", C.c_double)]
+
+
 CONTACT_DTYPE = np.dtype([
     ("objA", "i4"), ("childA", "i4"), ("objB", "i4"), ("childB", "i4"), ("cctype", "i4"), ("time", "f4"),
     ("dist", "f8"), ("n", "f8", 3), ("ptA", "f8", 3), ("ptB", "f8", 3), ("ptB1", "f8", 3)], align=True)
 assert CONTACT_DTYPE.itemsize == C.sizeof(OraContact)
+LIN_DTYPE = np.dtype([("t", "i4"), ("c", CONTACT_DTYPE), ("const0", "f8"), ("const1", "f8")], align=True)
+assert LIN_DTYPE.itemsize == C.sizeof(OraLin)
 
 
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
-class Scene:
-    """Flat scene: shapes, children (geometry instances) and objects (links with geometry)."""
-
-    def __init__(self):
-        self.kind, self.param, self.voff, self.vcnt = [], [], [], []
-        self.verts = []
-        self.child_shape, self.child_T = [], []
-        self.obj_off, self.obj_cnt, self.obj_compound, self.obj_group = [], [], [], []
-        self.obj_name = []
-
-    # -- shapes ----------------------------------------------------------------------------------------
-    def add_box(self, hx, hy, hz):
-        return self._shape(BOX, (hx, hy, hz, 0.0), None)
-
-    def add_sphere(self, r):
-        return self._shape(SPHERE, (r, 0, 0, 0), None)
-
-    def add_cylinder_z(self, r, half_h):
-        return self._shape(CYLZ, (r, half_h, 0, 0), None)
-
-    def add_hull(self, pts):
-        pts = np.asarray(pts, dtype=np.float32).reshape(-1, 3)
-        assert 1 <= len(pts) <= 64
-        return self._shape(HULL, (0, 0, 0, 0), pts)
-
-    def _shape(self, kind, param, pts):
-        self.kind.append(kind)
-        self.param.append(param)
-        self.voff.append(sum(len(v) for v in self.verts))
-        self.vcnt.append(0 if pts is None else len(pts))
-        if pts is not None:
-            self.verts.append(pts)
-        return len(self.kind) - 1
-
-    # -- objects ---------------------------------------------------------------------------------------
-    def add_object(self, children, group, compound=None, name=None):
-        """children: list of (shape_id, T7).  compound=None applies the reference's rule
-        (one geometry at identity -> bare shape; bullet_collision_checker.cpp:224)."""
-        if compound is None:
-            compound = not (len(children) == 1 and _is_identity(children[0][1]))
-        if not compound:
-            assert len(children) == 1
-        self.obj_off.append(len(self.child_shape))
-        self.obj_cnt.append(len(children))
-        self.obj_compound.append(int(compound))
-        self.obj_group.append(group)
-        self.obj_name.append(name or "obj%d" % len(self.obj_name))
-        for s, T in children:
-            self.child_shape.append(s)
-            self.child_T.append(tuple(float(x) for x in T))
-        return len(self.obj_off) - 1
-
-    @property
-    def n_objects(self):
-        return len(self.obj_off)
-
-    def finalize(self):
-        i4, f4, f8 = np.int32, np.float32, np.float64
-        a = self.arrays = dict(
-            kind=np.array(self.kind, i4), param=np.array(self.param, f4).reshape(-1, 4),
-            voff=np.array(self.voff, i4), vcnt=np.array(self.vcnt, i4),
-            verts=(np.concatenate(self.verts).astype(f4) if self.verts else np.zeros((1, 3), f4)),
-            child_shape=np.array(self.child_shape, i4), child_T=np.array(self.child_T, f8).reshape(-1, 7),
-            obj_off=np.array(self.obj_off, i4), obj_cnt=np.array(self.obj_cnt, i4),
-            obj_compound=np.array(self.obj_compound, i4), obj_group=np.array(self.obj_group, i4))
-        for k in a:
-            a[k] = np.ascontiguousarray(a[k])
-        s = OraScene()
-        s.n_shapes = len(a["kind"]); s.shape_kind = _p(a["kind"], C.c_int); s.shape_param = _p(a["param"], C.c_float)
-        s.shape_voff = _p(a["voff"], C.c_int); s.shape_vcnt = _p(a["vcnt"], C.c_int)
-        s.n_verts = len(self.verts) and int(a["verts"].shape[0]); s.verts = _p(a["verts"], C.c_float)
-        s.n_children = len(a["child_shape"]); s.child_shape = _p(a["child_shape"], C.c_int)
-        s.child_T = _p(a["child_T"], C.c_double)
-        s.n_objects = len(a["obj_off"]); s.obj_child_off = _p(a["obj_off"], C.c_int)
-        s.obj_child_cnt = _p(a["obj_cnt"], C.c_int); s.obj_compound = _p(a["obj_compound"], C.c_int)
-        s.obj_group = _p(a["obj_group"], C.c_int)
-        self.c = s
-        return self
+def make_c_scene(scene):
+    """ctypes view of a finalized trajopt_amd.model.Scene (arrays stay alive through scene.arrays)."""
+    a = scene.arrays
+    s = OraScene()
+    s.n_shapes = len(a["kind"]); s.shape_kind = _p(a["kind"], C.c_int); s.shape_param = _p(a["param"], C.c_float)
+    s.shape_voff = _p(a["voff"], C.c_int); s.shape_vcnt = _p(a["vcnt"], C.c_int)
+    s.n_verts = int(a["vcnt"].sum()); s.verts = _p(a["verts"], C.c_float)
+    s.n_children = len(a["child_shape"]); s.child_shape = _p(a["child_shape"], C.c_int)
+    s.child_T = _p(a["child_T"], C.c_double)
+    s.n_objects = len(a["obj_off"]); s.obj_child_off = _p(a["obj_off"], C.c_int)
+    s.obj_child_cnt = _p(a["obj_cnt"], C.c_int); s.obj_compound = _p(a["obj_compound"], C.c_int)
+    s.obj_group = _p(a["obj_group"], C.c_int)
+    return s
 
 
-def _is_identity(T, e=1e-6):
-    # isIdentity(), bullet_collision_checker.cpp:85-95
-    return (abs(T[4]) < e and abs(T[5]) < e and abs(T[6]) < e and abs(T[0] - 1) < e and abs(T[1]) < e
-            and abs(T[2]) < e and abs(T[3]) < e)
+def make_c_robot(robot):
+    """ctypes view of a finalized trajopt_amd.model.RobotModel."""
+    a = robot.arrays
+    r = OraRobot()
+    r.n_links = robot.n_links
+    r.parent = _p(a["parent"], C.c_int); r.jtype = _p(a["jtype"], C.c_int)
+    r.T_origin = _p(a["T_origin"], C.c_double); r.axis = _p(a["axis"], C.c_double)
+    r.dof = _p(a["dof"], C.c_int); r.mult = _p(a["mult"], C.c_double); r.offs = _p(a["offs"], C.c_double)
+    r.link_obj = _p(a["link_obj"], C.c_int)
+    r.n_dof = robot.n_dof; r.q_robot = _p(a["q_robot"], C.c_double)
+    for i in range(7):
+        r.base_T[i] = float(a["base_T"][i])
+    r.n_joint_inds = len(robot.joint_inds); r.joint_inds = _p(a["joint_inds"], C.c_int)
+    r.affine = robot.affine
+    for i in range(3):
+        r.rot_axis[i] = float(a["rot_axis"][i])
+    return r
 
 
 class World:
@@ -151,9 +112,21 @@ class World:
         f("cast_vs_all").argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int,
                                      C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(OraContact), C.c_int]
         self.f = f
-        self.h = f("create")(C.byref(scene.c))
+        self.cscene = make_c_scene(scene)
+        self.h = f("create")(C.byref(self.cscene))
         self.cap = cap
         self.buf = np.zeros(cap, CONTACT_DTYPE)
+        if prefix == "ora_":
+            lib.ora_counter.restype = C.c_long
+            lib.ora_counter.argtypes = [C.c_void_p, C.c_int]
+            for n in ("linearize_discrete", "linearize_cast"):
+                f(n).restype = C.c_int
+            lib.ora_linearize_discrete.argtypes = [C.c_void_p, C.POINTER(OraRobot), C.POINTER(C.c_double),
+                                                   C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(OraLin),
+                                                   C.POINTER(C.c_double), C.c_int]
+            lib.ora_linearize_cast.argtypes = [C.c_void_p, C.POINTER(OraRobot), C.POINTER(C.c_double),
+                                               C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(OraLin),
+                                               C.POINTER(C.c_double), C.c_int]
 
     def close(self):
         if self.h:
@@ -187,6 +160,54 @@ class World:
                                   _p(T1, C.c_double), self.buf.ctypes.data_as(C.POINTER(OraContact)), self.cap)
         assert n <= self.cap
         return self.buf[:n].copy()
+
+    # -- oracle only: full linearization (FK + contacts + Jacobian projection) ---------------------------
+    def counter(self, which):
+        return int(self.lib.ora_counter(self.h, which))
+
+    def linearize(self, robot, static_T, dofs, cast=False, gap=1, mask=-1):
+        """-> (records LIN_DTYPE[n], grads float64[n,2,K])"""
+        crobot = make_c_robot(robot)
+        K = robot.K
+        dofs = np.ascontiguousarray(dofs, np.float64).reshape(-1, K)
+        static_T = np.ascontiguousarray(static_T, np.float64).reshape(-1, 7)
+        assert len(static_T) == self.scene.n_objects
+        out = np.zeros(self.cap, LIN_DTYPE)
+        grads = np.zeros((self.cap, 2, K))
+        if cast:
+            n = self.lib.ora_linearize_cast(self.h, C.byref(crobot), _p(static_T, C.c_double), _p(dofs, C.c_double),
+                                            len(dofs), gap, out.ctypes.data_as(C.POINTER(OraLin)),
+                                            _p(grads, C.c_double), self.cap)
+        else:
+            n = self.lib.ora_linearize_discrete(self.h, C.byref(crobot), _p(static_T, C.c_double),
+                                                _p(dofs, C.c_double), len(dofs), int(mask),
+                                                out.ctypes.data_as(C.POINTER(OraLin)), _p(grads, C.c_double), self.cap)
+        assert n <= self.cap, "oracle result buffer too small"
+        return out[:n].copy(), grads[:n].copy()
+
+
+def oracle_fk(robot, dofs):
+    lib = load_oracle()
+    lib.ora_fk.argtypes = [C.POINTER(OraRobot), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    cr = make_c_robot(robot)
+    dofs = np.ascontiguousarray(dofs, np.float64)
+    out = np.zeros((robot.n_links, 7))
+    lib.ora_fk(C.byref(cr), _p(dofs, C.c_double), _p(out, C.c_double))
+    return out
+
+
+def oracle_position_jacobian(robot, dofs, link, pt):
+    lib = load_oracle()
+    lib.ora_position_jacobian.argtypes = [C.POINTER(OraRobot), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int,
+                                          C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    cr = make_c_robot(robot)
+    dofs = np.ascontiguousarray(dofs, np.float64)
+    linkT = oracle_fk(robot, dofs)
+    pt = np.ascontiguousarray(pt, np.float64)
+    J = np.zeros((3, robot.K))
+    lib.ora_position_jacobian(C.byref(cr), _p(linkT, C.c_double), _p(dofs, C.c_double), int(link), _p(pt, C.c_double),
+                              _p(J, C.c_double))
+    return J
 
 
 def ref_available():

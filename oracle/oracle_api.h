@@ -57,6 +57,47 @@ typedef struct ora_contact {
   double ptA[3], ptB[3], ptB1[3];
 } ora_contact;
 
+
+/* Flattened kinematic model.  OpenRAVE (FK, Jacobians) is absent from /root/reference and from this image, so the
+ * conventions below are the build's own, chosen to follow what configuration_space.cpp:12-23,83-133 relies on:
+ *   link i hangs off link parent[i] (parents precede children; parent -1 = the base link);
+ *   T_world_link = T_world_parent * T_origin[i] * Motion(jtype[i], axis[i], value)   (URDF convention)
+ *   value = mult[i]*q_robot[dof[i]] + offs[i]; revolute: rotation about axis by value, prismatic: translation
+ *   the optimisation vector is [q_robot[joint_inds[0..nj)], affine values in the order X, Y, Z, RotationAxis]
+ *   (RaveGetTransformFromAffineDOFValues order); with affine DOFs the base transform starts from identity
+ *   (configuration_space.cpp:14-16), else it is base_T.
+ * Transforms compose in fp64 quaternion form (q = qa*qb renormalised, t = qa.rotate(tb)+ta). */
+enum { ORA_J_FIXED = 0, ORA_J_REVOLUTE = 1, ORA_J_PRISMATIC = 2 };
+enum { ORA_DOF_X = 1, ORA_DOF_Y = 2, ORA_DOF_Z = 4, ORA_DOF_ROTAXIS = 8 };
+typedef struct ora_robot {
+  int n_links;
+  const int *parent;       /* [n_links]                                                       */
+  const int *jtype;        /* [n_links] ORA_J_*                                               */
+  const double *T_origin;  /* [n_links*7]                                                     */
+  const double *axis;      /* [n_links*3] unit, in the link's own (joint) frame               */
+  const int *dof;          /* [n_links] robot DOF driving the joint, -1 if fixed              */
+  const double *mult;      /* [n_links]                                                       */
+  const double *offs;      /* [n_links]                                                       */
+  const int *link_obj;     /* [n_links] scene object holding the link's geometry, or -1       */
+  int n_dof;
+  const double *q_robot;   /* [n_dof] current values of all robot DOFs (inactive ones stay)   */
+  double base_T[7];
+  int n_joint_inds;
+  const int *joint_inds;   /* [n_joint_inds] active robot DOFs                                 */
+  int affine;              /* ORA_DOF_* mask                                                   */
+  double rot_axis[3];
+} ora_robot;
+
+/* One linearised contact: the reference's Collision plus the AffExpr pieces of collision_terms.cpp:37-80.
+ *   discrete:  expr(x)      = const0 + grad0 . x_t
+ *   cast:      expr(x0, x1) = (1-time)*(const0 + grad0 . x_t) + time*(const1 + grad1 . x_t1)
+ * grad0/grad1 live in a separate [n][2][K] array. */
+typedef struct ora_lin {
+  int t;           /* timestep (cast: the first of the pair) */
+  ora_contact c;
+  double const0, const1;
+} ora_lin;
+
 #ifdef __cplusplus
 }
 #endif
