@@ -1,0 +1,140 @@
+/*
+ * trajopt_hipcc.h -- C-ABI of libtrajopt_hipcc.so, the MI355X (gfx950) collision-cost linearization engine.
+ *
+ * This is the drop-in boundary for ONE path of joschu/trajopt: everything underneath
+ *   trajopt::CollisionChecker::{LinksVsAll, CastVsAll}      src/trajopt/collision_checker.hpp:40-84
+ *   CollisionsToDistanceExpressions                         src/trajopt/collision_terms.cpp:37-80
+ * A C++ adapter `HIPCollisionChecker : trajopt::CollisionChecker` binds these entry points; no
+ * OpenRAVE, Bullet or torch type crosses the boundary: plain pointers and sizes only.  Every function returns 0 on
+ * success or a negative TOHC_E_* code; tohc_last_error() gives the message (no exceptions cross; the reference
+ * throws std::runtime_error, collision_checker.hpp:57-62, which the adapter re-creates from the code).
+ *
+ * Threading: like the reference checker (one per environment, not re-entrant) a handle serialises its calls; use one
+ * handle per host thread / per GPU.
+ *
+ * Transforms are OpenRAVE style, 7 doubles (qw qx qy qz tx ty tz); the engine rounds them to fp32 and builds the
+ * rotation matrix exactly as toBt() + btMatrix3x3::setRotation do (bullet_collision_checker.cpp:72-83).
+ */
+#ifndef TRAJOPT_HIPCC_H
+#define TRAJOPT_HIPCC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tohc_engine tohc_engine; /* opaque */
+
+enum {
+  TOHC_OK = 0,
+  TOHC_E_INVALID = -1,   /* bad argument / inconsistent sizes            */
+  TOHC_E_HIP = -2,       /* a HIP runtime call failed                    */
+  TOHC_E_CAPACITY = -3,  /* pair list or result slab too small           */
+  TOHC_E_STATE = -4,     /* call order (e.g. query before upload)        */
+  TOHC_E_UNSUPPORTED = -5
+};
+
+enum { TOHC_BOX = 0, TOHC_HULL = 1 };                   /* createShapePrimitive, bullet_collision_checker.cpp:134-212 */
+enum { TOHC_GROUP_ROBOT = 1, TOHC_GROUP_KINBODY = 2 };  /* CollisionFilterGroups, collision_checker.hpp:32-35        */
+enum { TOHC_CC_NONE = 0, TOHC_CC_TIME0 = 1, TOHC_CC_TIME1 = 2, TOHC_CC_BETWEEN = 3 }; /* CastCollisionType, :12-17  */
+enum { TOHC_J_FIXED = 0, TOHC_J_REVOLUTE = 1, TOHC_J_PRISMATIC = 2 };
+enum { TOHC_DOF_X = 1, TOHC_DOF_Y = 2, TOHC_DOF_Z = 4, TOHC_DOF_ROTAXIS = 8 }; /* OpenRAVE DOFAffine, configuration_space.cpp:47-78 */
+
+/* One linearised contact = the reference's Collision (collision_checker.hpp:19-29) + the AffExpr pieces of
+ * CollisionsToDistanceExpressions (collision_terms.cpp:37-80).  152 bytes; gradients live in a parallel
+ * double[n][2][K] array.
+ *   discrete:  dist(x)      ~ const0 + grad0 . x_t
+ *   cast:      dist(x0, x1) ~ (1-time)*(const0 + grad0 . x_t) + time*(const1 + grad1 . x_{t+gap})
+ * idA/idB are object (link) ids, childA/childB geometry indices inside the link; A/B follow Bullet's GJK roles
+ * (for cast contacts B is the swept robot link, bullet_collision_checker.cpp:913-917). */
+typedef struct tohc_record {
+  int32_t problem, t;
+  int32_t idA, childA, idB, childB;
+  int32_t cctype;
+  float time;
+  double dist;
+  double n[3];               /* normalB2A */
+  double ptA[3], ptB[3], ptB1[3];
+  double const0, const1;
+} tohc_record;
+
+typedef struct tohc_counters {
+  int64_t aabb_tests;   /* (timestep, query child, other child) tuples examined by the broadphase    */
+  int64_t pair_evals;   /* tuples that survived the cull and got a GJK evaluation                     */
+  int64_t epa_evals;    /* of those, how many went through GJK2+EPA                                   */
+  int64_t contacts;     /* records written                                                            */
+  double ms_last_call;  /* device time of the last batch call (HIP events on the engine's stream)     */
+} tohc_counters;
+
+/* replaces CreateCollisionChecker(env)                       src/trajopt/bullet_collision_checker.cpp:1036-1039 */
+int tohc_create(tohc_engine **out, int device);
+void tohc_destroy(tohc_engine *e);
+const char *tohc_last_error(const tohc_engine *e);
+
+/* replaces AddKinBody / CollisionObjectFromLink / createShapePrimitive   bullet_collision_checker.cpp:134-255,535-561
+ *   shapes:   kind, param[4] (box: half extents as OpenRAVE gives them), vertex range into the SoA vertex arrays
+ *   children: one geometry of a link = shape + local transform (geom->GetTransform())
+ *   objects:  one link with geometry; compound!=0 <=> btCompoundShape (not "one geometry at identity");
+ *             group = RobotFilter / KinBodyFilter; static_T = world transform used when the object is not driven
+ *             by the uploaded robot. */
+int tohc_upload_scene(tohc_engine *e, int n_shapes, const int32_t *shape_kind, const float *shape_param /*[n][4]*/,
+                      const int32_t *shape_voff, const int32_t *shape_vcnt, int n_verts, const float *vx, const float *vy,
+                      const float *vz, int n_children, const int32_t *child_shape, const double *child_T /*[n][7]*/,
+                      int n_objects, const int32_t *obj_child_off, const int32_t *obj_child_cnt, const int32_t *obj_compound,
+                      const int32_t *obj_group, const double *obj_static_T /*[n][7]*/);
+
+/* replaces RobotAndDOF (configuration_space.hpp) + OpenRAVE's FK / CalculateActiveJacobian  configuration_space.cpp:12-23,83-133
+ * Flattened joint tree, parents first; conventions in DESIGN.md ("FK model").  link_obj[i] = scene object carrying the
+ * link's geometry (-1: none).  The optimisation vector is [q[joint_inds]..., affine X, Y, Z, RotationAxis]. */
+int tohc_upload_robot(tohc_engine *e, int n_links, const int32_t *parent, const int32_t *jtype, const double *T_origin /*[n][7]*/,
+                      const double *axis /*[n][3]*/, const int32_t *dof, const double *mult, const double *offs,
+                      const int32_t *link_obj, int n_dof, const double *q_robot, const double *base_T /*[7]*/,
+                      int n_joint_inds, const int32_t *joint_inds, int affine, const double *rot_axis /*[3]*/);
+
+/* replaces m_allowedCollisionMatrix / Exclude|IncludeCollisionPair       bullet_collision_checker.cpp:342-351,606-627
+ * allowed[i*n_objects+j] != 0 <=> object i (as query) may collide with object j. */
+int tohc_set_allowed_matrix(tohc_engine *e, int n_objects, const uint8_t *allowed);
+
+/* replaces BulletCollisionChecker::SetContactDistance / GetContactDistance    bullet_collision_checker.cpp:449-460 */
+int tohc_set_contact_distance(tohc_engine *e, float d);
+double tohc_get_contact_distance(const tohc_engine *e);
+
+/* replaces LinksVsAll per timestep + SingleTimestepCollisionEvaluator::CalcDistExpressions
+ *                     bullet_collision_checker.cpp:500-524, collision_terms.cpp:118-136
+ * dofs: [B][T][K] fp64, B independent problems (multi-start) over the same scene and robot.  Query links are the
+ * robot's affected links with geometry (GetAffectedLinks, configuration_space.cpp:110-118).  filter_mask as in
+ * LinksVsAll (-1: everything, incl. self collision).  want_jacobians=0 skips the gradient epilogue (CalcDists).
+ * On return *records / *grads point into a pinned result slab owned by the engine, valid until the next call on
+ * this handle; records are in canonical order (problem, t, idA, childA, idB, childB). */
+int tohc_links_vs_all_batch(tohc_engine *e, const double *dofs, int B, int T, int filter_mask, int want_jacobians,
+                            const tohc_record **records, const double **grads /*[n][2][K]*/, int *n_records);
+
+/* replaces CastVsAll per timestep pair + CastCollisionEvaluator::CalcDistExpressions
+ *                     bullet_collision_checker.cpp:974-1023, collision_terms.cpp:64-80,156-168
+ * one swept check per (problem, t, t+gap), t in [0, T-gap); record.t is the first timestep of the pair. */
+int tohc_cast_vs_all_batch(tohc_engine *e, const double *dofs, int B, int T, int gap, int want_jacobians,
+                           const tohc_record **records, const double **grads, int *n_records);
+
+/* replaces LinksVsAll / CastVsAll on explicit poses (no robot model needed): the reference reads poses from the
+ * OpenRAVE environment at call time (UpdateBulletFromRave, bullet_collision_checker.cpp:648-653).
+ * obj_T: [n_sets][n_objects][7]; query: object ids.  No Jacobians (no kinematic model). */
+int tohc_links_vs_all_poses(tohc_engine *e, const double *obj_T, int n_sets, const int32_t *query, int n_query, int filter_mask,
+                            const tohc_record **records, int *n_records);
+/* cast_T1: [n_sets][n_query][7] = pose of each query link at the end of the sweep (start = its pose in obj_T). */
+int tohc_cast_vs_all_poses(tohc_engine *e, const double *obj_T, const double *cast_T1, int n_sets, const int32_t *query,
+                           int n_query, const tohc_record **records, int *n_records);
+
+/* device FK only (diagnostics / tests): link_T [B*T][n_links][7] */
+int tohc_forward_kinematics(tohc_engine *e, const double *dofs, int n_cfg, double *link_T);
+
+int tohc_get_counters(const tohc_engine *e, tohc_counters *out);
+
+/* capacity knobs (defaults sized for SURVEY config 4 on one MI355X) */
+int tohc_set_capacity(tohc_engine *e, int64_t max_pairs, int64_t max_records);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1180 @@
+// tohc_narrow.h -- narrowphase device code: GJK closest points, GJK2+EPA penetration, swept-hull support, cast contact
+// classification.  One GROUP of G lanes (G = 16 or 64, a power of two <= the 64-lane wavefront) works on one
+// (timestep, query child, other child) pair:
+//   * hull vertices live in REGISTERS, vertex i in lane i%G slot i/G; a support query is a lane-parallel dot product
+//     followed by a cross-lane arg-max with lowest-index tie-break (btVector3::maxDot is a strict '>' scan from 0);
+//   * the simplex / EPA bookkeeping is group-uniform: every lane of the group runs the same scalar control flow on
+//     the same values, so no lane ever reads what another lane wrote -- except through the arg-max / broadcast;
+//   * EPA's face and vertex pools live in LDS (EpaMem, one per group).
+// Arithmetic follows Bullet's fp32 operation order line by line (the reference's vendored, patched Bullet):
+//   [gjk] ext/bullet/src/BulletCollision/NarrowPhaseCollision/btGjkPairDetector.cpp:82-452
+//   [vss] .../btVoronoiSimplexSolver.cpp:35-608            [epa] .../btGjkEpa2.cpp:142-945
+//   [pds] .../btGjkEpaPenetrationDepthSolver.cpp:24-64     [cvx] .../CollisionShapes/btConvexShape.cpp:64-308
+//   [bcc] src/trajopt/bullet_collision_checker.cpp:98-131 (GetAverageSupport), :816-882 (CastHullShape), :894-972
+// Margins: boxes and hulls carry margin 0 (MARGIN, bcc:23), so the "+ margin * n" terms of the reference are exact
+// no-ops and are left out; sphere / cylinder geometry is not supported yet (tohc_upload_scene rejects it).
+#pragma once
+#include <float.h>
+#include <limits.h>
+#include <stdint.h>
+
+#include "tohc_math.h"
+
+namespace tohc {
+
+// ---------------------------------------------------------------------------------------------------------------
+// group primitives
+// ---------------------------------------------------------------------------------------------------------------
+template <int G>
+struct Grp {
+#if defined(__HIPCC__)
+  static TOHC_DEV int lane() { return (int)(threadIdx.x & (G - 1)); }
+  static TOHC_DEV float bcast(float v, int src) { return __shfl(v, src, G); }
+  static TOHC_DEV void argmax(float &v, int &i) {
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) {
+      float ov = __shfl_xor(v, m, G);
+      int oi = __shfl_xor(i, m, G);
+      bool take = (ov > v) || (ov == v && oi < i);
+      v = take ? ov : v;
+      i = take ? oi : i;
+    }
+  }
+  static TOHC_DEV float sum_ordered(float v, int n) {  // sum of lanes' v over vertex order is not needed; placeholder
+    return v;
+  }
+#else
+  static int lane() { return 0; }
+  static float bcast(float v, int) { return v; }
+  static void argmax(float &, int &) {}
+#endif
+};
+
+enum { KIND_BOX = 0, KIND_HULL = 1 };
+
+template <int G>
+struct Cvx {
+  static constexpr int VPL = 64 / G;
+  int kind, cast, n;
+  V3 dims;  // box: m_implicitShapeDimensions after the margin round trip (host computes it, engine.hip)
+  float x[VPL], y[VPL], z[VPL];
+  Xf t01;   // cast: T_0_1 = T_w_0^-1 * T_w_1
+};
+
+template <int G>
+TOHC_DEV void cvxLoad(Cvx<G> &c, int kind, V3 dims, const float *vx, const float *vy, const float *vz, int voff, int n) {
+  c.kind = kind;
+  c.cast = 0;
+  c.n = n;
+  c.dims = dims;
+  const int gl = Grp<G>::lane();
+#pragma unroll
+  for (int s = 0; s < Cvx<G>::VPL; ++s) {
+    int i = s * G + gl;
+    bool in = (kind == KIND_HULL) && (i < n);
+    c.x[s] = in ? vx[voff + i] : 0.0f;
+    c.y[s] = in ? vy[voff + i] : 0.0f;
+    c.z[s] = in ? vz[voff + i] : 0.0f;
+  }
+}
+
+TOHC_DEV float fsel(float a, float b, float c) { return a >= 0 ? b : c; }  // btScalar.h:468-473
+
+// btVector3::maxDot (btVector3.h:1003-1018): strict '>' from index 0 => the lowest index among equal maxima
+template <int G>
+TOHC_DEV V3 hullMaxDot(const Cvx<G> &c, V3 d) {
+  const int gl = Grp<G>::lane();
+  float best = -INFINITY;
+  int bi = INT_MAX;
+#pragma unroll
+  for (int s = 0; s < Cvx<G>::VPL; ++s) {
+    int i = s * G + gl;
+    float dt = c.x[s] * d.x + c.y[s] * d.y + c.z[s] * d.z;
+    if (i < c.n && dt > best) { best = dt; bi = i; }
+  }
+  Grp<G>::argmax(best, bi);
+  if (bi == INT_MAX) bi = 0;
+  const int slot = bi / G, src = bi % G;
+  float sx = c.x[0], sy = c.y[0], sz = c.z[0];
+#pragma unroll
+  for (int s = 1; s < Cvx<G>::VPL; ++s)
+    if (s == slot) { sx = c.x[s]; sy = c.y[s]; sz = c.z[s]; }
+  return mk(Grp<G>::bcast(sx, src), Grp<G>::bcast(sy, src), Grp<G>::bcast(sz, src));
+}
+
+// localGetSupportVertexWithoutMarginNonVirtual for box / hull [cvx:120-296]
+template <int G>
+TOHC_DEV V3 supPlainNV(const Cvx<G> &c, V3 d) {
+  if (c.kind == KIND_BOX) return mk(fsel(-d.x, -c.dims.x, c.dims.x), fsel(-d.y, -c.dims.y, c.dims.y), fsel(-d.z, -c.dims.z, c.dims.z));
+  return hullMaxDot<G>(c, d);
+}
+// the VIRTUAL localGetSupportingVertex CastHullShape calls on its inner shape: box tie rule d >= 0 -> +h (btBoxShape.h:50-59)
+template <int G>
+TOHC_DEV V3 supPlainVirtual(const Cvx<G> &c, V3 d) {
+  if (c.kind == KIND_BOX) return mk(fsel(d.x, c.dims.x, -c.dims.x), fsel(d.y, c.dims.y, -c.dims.y), fsel(d.z, c.dims.z, -c.dims.z));
+  return hullMaxDot<G>(c, d);
+}
+template <int G>
+TOHC_DEV V3 supNV(const Cvx<G> &c, V3 d) {
+  if (!c.cast) return supPlainNV<G>(c, d);
+  V3 sv0 = supPlainVirtual<G>(c, d);  // CastHullShape::localGetSupportingVertex [bcc:826-830]
+  V3 sv1 = xfApply(c.t01, supPlainVirtual<G>(c, mulVM(d, c.t01.b)));
+  return (dot(d, sv0) > dot(d, sv1)) ? sv0 : sv1;
+}
+TOHC_DEV V3 normalizedOrMinus1(V3 d) {  // [cvx:298-306]
+  if (len2(d) < (FLT_EPSILON * FLT_EPSILON)) d = mk(-1, -1, -1);
+  return vdiv(d, len(d));
+}
+template <int G>
+TOHC_DEV V3 supWithMarginNV(const Cvx<G> &c, V3 d) { return supNV<G>(c, normalizedOrMinus1(d)); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// btVoronoiSimplexSolver [vss]; arrays are only ever indexed with compile-time constants (select chains), so they
+// stay in registers
+// ---------------------------------------------------------------------------------------------------------------
+struct SubRes {
+  V3 closest;
+  bool used[4];
+  float bc[4];
+  bool degenerate;
+};
+struct Simplex {
+  int n;
+  V3 W[4], P[4], Q[4];
+  V3 cP1, cP2, cV, lastW;
+  bool cachedValid, needsUpdate;
+  SubRes bc;
+};
+
+TOHC_DEV V3 pick(const V3 *a, int i) {
+  V3 r = a[0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k)
+    if (k == i) r = a[k];
+  return r;
+}
+TOHC_DEV void put(V3 *a, int i, V3 v) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k == i) a[k] = v;
+}
+TOHC_DEV void subResReset(SubRes &r) {
+  r.degenerate = false;
+  r.bc[0] = r.bc[1] = r.bc[2] = r.bc[3] = 0;
+  r.used[0] = r.used[1] = r.used[2] = r.used[3] = false;
+}
+TOHC_DEV void setBC(SubRes &r, float a, float b, float c, float d) { r.bc[0] = a; r.bc[1] = b; r.bc[2] = c; r.bc[3] = d; }
+TOHC_DEV bool subResValid(const SubRes &r) { return r.bc[0] >= 0 && r.bc[1] >= 0 && r.bc[2] >= 0 && r.bc[3] >= 0; }
+TOHC_DEV void vssReset(Simplex &s) {
+  s.cachedValid = false;
+  s.n = 0;
+  s.needsUpdate = true;
+  s.lastW = mk(1e18f, 1e18f, 1e18f);
+  subResReset(s.bc);
+  for (int k = 0; k < 4; ++k) s.W[k] = s.P[k] = s.Q[k] = mk(0, 0, 0);
+  s.cP1 = s.cP2 = s.cV = mk(0, 0, 0);
+}
+template <int I>
+TOHC_DEV void vssRemove(Simplex &s) {
+  s.n--;
+  s.W[I] = pick(s.W, s.n);
+  s.P[I] = pick(s.P, s.n);
+  s.Q[I] = pick(s.Q, s.n);
+}
+TOHC_DEV void vssReduce(Simplex &s, const bool *used) {  // [vss:45-59]
+  if (s.n >= 4 && !used[3]) vssRemove<3>(s);
+  if (s.n >= 3 && !used[2]) vssRemove<2>(s);
+  if (s.n >= 2 && !used[1]) vssRemove<1>(s);
+  if (s.n >= 1 && !used[0]) vssRemove<0>(s);
+}
+TOHC_DEV void vssAdd(Simplex &s, V3 w, V3 p, V3 q) {
+  s.lastW = w;
+  s.needsUpdate = true;
+  put(s.W, s.n, w);
+  put(s.P, s.n, p);
+  put(s.Q, s.n, q);
+  s.n++;
+}
+TOHC_DEV bool vssInSimplex(const Simplex &s, V3 w) {  // [vss:283-305]; BT_USE_EQUAL_VERTEX_THRESHOLD is defined (vss.h:28)
+  bool found = false;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < s.n && len2(w - s.W[i]) <= 0.0001f) found = true;
+  if (veq(w, s.lastW)) return true;
+  return found;
+}
+
+TOHC_DEV void closestPtTriangle(V3 p, V3 a, V3 b, V3 c, SubRes &r) {  // [vss:330-423]
+  r.used[0] = r.used[1] = r.used[2] = r.used[3] = false;
+  V3 ab = b - a, ac = c - a, ap = p - a;
+  float d1 = dot(ab, ap), d2 = dot(ac, ap);
+  if (d1 <= 0.0f && d2 <= 0.0f) { r.closest = a; r.used[0] = true; setBC(r, 1, 0, 0, 0); return; }
+  V3 bp = p - b;
+  float d3 = dot(ab, bp), d4 = dot(ac, bp);
+  if (d3 >= 0.0f && d4 <= d3) { r.closest = b; r.used[1] = true; setBC(r, 0, 1, 0, 0); return; }
+  float vc = d1 * d4 - d3 * d2;
+  if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) {
+    float v = d1 / (d1 - d3);
+    r.closest = a + ab * v;
+    r.used[0] = r.used[1] = true;
+    setBC(r, 1 - v, v, 0, 0);
+    return;
+  }
+  V3 cp = p - c;
+  float d5 = dot(ab, cp), d6 = dot(ac, cp);
+  if (d6 >= 0.0f && d5 <= d6) { r.closest = c; r.used[2] = true; setBC(r, 0, 0, 1, 0); return; }
+  float vb = d5 * d2 - d1 * d6;
+  if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) {
+    float w = d2 / (d2 - d6);
+    r.closest = a + ac * w;
+    r.used[0] = r.used[2] = true;
+    setBC(r, 1 - w, 0, w, 0);
+    return;
+  }
+  float va = d3 * d6 - d5 * d4;
+  if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) {
+    float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    r.closest = b + (c - b) * w;
+    r.used[1] = r.used[2] = true;
+    setBC(r, 0, 1 - w, w, 0);
+    return;
+  }
+  float denom = 1.0f / (va + vb + vc);
+  float v = vb * denom, w = vc * denom;
+  r.closest = (a + ab * v) + ac * w;
+  r.used[0] = r.used[1] = r.used[2] = true;
+  setBC(r, 1 - v - w, v, w, 0);
+}
+
+TOHC_DEV int pointOutsideOfPlane(V3 p, V3 a, V3 b, V3 c, V3 d) {  // [vss:430-454]
+  V3 normal = cross(b - a, c - a);
+  float signp = dot(p - a, normal);
+  float signd = dot(d - a, normal);
+  if (signd * signd < (1e-4f * 1e-4f)) return -1;
+  return signp * signd < 0.0f;
+}
+
+TOHC_DEV bool closestPtTetrahedron(V3 p, V3 a, V3 b, V3 c, V3 d, SubRes &fr) {  // [vss:457-608]
+  SubRes tr;
+  fr.closest = p;
+  fr.used[0] = fr.used[1] = fr.used[2] = fr.used[3] = true;
+  int oABC = pointOutsideOfPlane(p, a, b, c, d);
+  int oACD = pointOutsideOfPlane(p, a, c, d, b);
+  int oADB = pointOutsideOfPlane(p, a, d, b, c);
+  int oBDC = pointOutsideOfPlane(p, b, d, c, a);
+  if (oABC < 0 || oACD < 0 || oADB < 0 || oBDC < 0) { fr.degenerate = true; return false; }
+  if (!oABC && !oACD && !oADB && !oBDC) return false;
+  float best = FLT_MAX;
+  if (oABC) {
+    closestPtTriangle(p, a, b, c, tr);
+    V3 q = tr.closest;
+    float sq = dot(q - p, q - p);
+    if (sq < best) {
+      best = sq; fr.closest = q;
+      fr.used[0] = tr.used[0]; fr.used[1] = tr.used[1]; fr.used[2] = tr.used[2]; fr.used[3] = false;
+      setBC(fr, tr.bc[0], tr.bc[1], tr.bc[2], 0);
+    }
+  }
+  if (oACD) {
+    closestPtTriangle(p, a, c, d, tr);
+    V3 q = tr.closest;
+    float sq = dot(q - p, q - p);
+    if (sq < best) {
+      best = sq; fr.closest = q;
+      fr.used[0] = tr.used[0]; fr.used[1] = false; fr.used[2] = tr.used[1]; fr.used[3] = tr.used[2];
+      setBC(fr, tr.bc[0], 0, tr.bc[1], tr.bc[2]);
+    }
+  }
+  if (oADB) {
+    closestPtTriangle(p, a, d, b, tr);
+    V3 q = tr.closest;
+    float sq = dot(q - p, q - p);
+    if (sq < best) {
+      best = sq; fr.closest = q;
+      fr.used[0] = tr.used[0]; fr.used[1] = tr.used[2]; fr.used[2] = false; fr.used[3] = tr.used[1];
+      setBC(fr, tr.bc[0], tr.bc[2], 0, tr.bc[1]);
+    }
+  }
+  if (oBDC) {
+    closestPtTriangle(p, b, d, c, tr);
+    V3 q = tr.closest;
+    float sq = dot(q - p, q - p);
+    if (sq < best) {
+      best = sq; fr.closest = q;
+      fr.used[0] = false; fr.used[1] = tr.used[0]; fr.used[2] = tr.used[2]; fr.used[3] = tr.used[1];
+      setBC(fr, 0, tr.bc[0], tr.bc[2], tr.bc[1]);
+    }
+  }
+  return true;
+}
+
+TOHC_DEV bool vssUpdate(Simplex &s) {  // updateClosestVectorAndPoints [vss:90-240]
+  if (!s.needsUpdate) return s.cachedValid;
+  subResReset(s.bc);
+  s.needsUpdate = false;
+  const V3 O = mk(0, 0, 0);
+  switch (s.n) {
+    case 0: s.cachedValid = false; break;
+    case 1:
+      s.cP1 = s.P[0];
+      s.cP2 = s.Q[0];
+      s.cV = s.cP1 - s.cP2;
+      subResReset(s.bc);
+      setBC(s.bc, 1, 0, 0, 0);
+      s.cachedValid = subResValid(s.bc);
+      break;
+    case 2: {
+      V3 from = s.W[0], to = s.W[1];
+      V3 diff = O - from;
+      V3 v = to - from;
+      float t = dot(v, diff);
+      if (t > 0) {
+        float dotVV = dot(v, v);
+        if (t < dotVV) {
+          t /= dotVV;
+          diff = diff - v * t;
+          s.bc.used[0] = true; s.bc.used[1] = true;
+        } else {
+          t = 1;
+          diff = diff - v;
+          s.bc.used[1] = true;
+        }
+      } else {
+        t = 0;
+        s.bc.used[0] = true;
+      }
+      setBC(s.bc, 1 - t, t, 0, 0);
+      s.cP1 = s.P[0] + (s.P[1] - s.P[0]) * t;
+      s.cP2 = s.Q[0] + (s.Q[1] - s.Q[0]) * t;
+      s.cV = s.cP1 - s.cP2;
+      vssReduce(s, s.bc.used);
+      s.cachedValid = subResValid(s.bc);
+      break;
+    }
+    case 3: {
+      closestPtTriangle(O, s.W[0], s.W[1], s.W[2], s.bc);
+      const float *b = s.bc.bc;
+      s.cP1 = (s.P[0] * b[0] + s.P[1] * b[1]) + s.P[2] * b[2];
+      s.cP2 = (s.Q[0] * b[0] + s.Q[1] * b[1]) + s.Q[2] * b[2];
+      s.cV = s.cP1 - s.cP2;
+      vssReduce(s, s.bc.used);
+      s.cachedValid = subResValid(s.bc);
+      break;
+    }
+    case 4: {
+      bool sep = closestPtTetrahedron(O, s.W[0], s.W[1], s.W[2], s.W[3], s.bc);
+      if (sep) {
+        const float *b = s.bc.bc;
+        s.cP1 = ((s.P[0] * b[0] + s.P[1] * b[1]) + s.P[2] * b[2]) + s.P[3] * b[3];
+        s.cP2 = ((s.Q[0] * b[0] + s.Q[1] * b[1]) + s.Q[2] * b[2]) + s.Q[3] * b[3];
+        s.cV = s.cP1 - s.cP2;
+        vssReduce(s, s.bc.used);
+      } else {
+        if (s.bc.degenerate) {
+          s.cachedValid = false;
+        } else {
+          s.cachedValid = true;
+          s.cV = O;
+        }
+        break;
+      }
+      s.cachedValid = subResValid(s.bc);
+      break;
+    }
+    default: s.cachedValid = false;
+  }
+  return s.cachedValid;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GJK main loop [gjk:82-332].  Returns the state the EPA stage needs.
+// ---------------------------------------------------------------------------------------------------------------
+struct GjkState {
+  bool isValid, needEpa;
+  float distance;
+  V3 normalInB, pointOnB;   // pointOnB in the midpoint-shifted frame
+  V3 offset;
+  int iters;
+};
+
+template <int G>
+TOHC_DEV void gjkMain(const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &tB, float maxDist2, GjkState &st) {
+  float distance = 0;
+  V3 normalInB = mk(0, 0, 0), pointOnB = mk(0, 0, 0);
+  Xf lA = tA, lB = tB;
+  V3 offset = (lA.o + lB.o) * 0.5f;
+  lA.o = lA.o - offset;
+  lB.o = lB.o - offset;
+  int curIter = 0;
+  const int maxIter = 1000;
+  V3 sep = mk(0, 1, 0);
+  bool isValid = false, checkSimplex = false;
+  int degenerate = 0;
+  float squaredDistance = 1e18f, delta = 0;
+  Simplex sx;
+  vssReset(sx);
+  for (;;) {
+    V3 sepA = mulVM(-sep, tA.b);
+    V3 sepB = mulVM(sep, tB.b);
+    V3 pInA = supNV<G>(A, sepA);
+    V3 qInB = supNV<G>(B, sepB);
+    V3 pW = xfApply(lA, pInA);
+    V3 qW = xfApply(lB, qInB);
+    V3 w = pW - qW;
+    delta = dot(sep, w);
+    if ((delta > 0.0f) && (delta * delta > squaredDistance * maxDist2)) { degenerate = 10; checkSimplex = true; break; }
+    if (vssInSimplex(sx, w)) { degenerate = 1; checkSimplex = true; break; }
+    float f0 = squaredDistance - delta;
+    float f1 = squaredDistance * 1.0e-6f;
+    if (f0 <= f1) { degenerate = (f0 <= 0.0f) ? 2 : 11; checkSimplex = true; break; }
+    vssAdd(sx, w, pW, qW);
+    bool ok = vssUpdate(sx);
+    V3 newSep = sx.cV;
+    if (!ok) { degenerate = 3; checkSimplex = true; break; }
+    if (len2(newSep) < 1.0e-6f) { sep = newSep; degenerate = 6; checkSimplex = true; break; }
+    float prev = squaredDistance;
+    squaredDistance = len2(newSep);
+    if (prev - squaredDistance <= FLT_EPSILON * prev) { checkSimplex = true; degenerate = 12; break; }
+    sep = newSep;
+    if (curIter++ > maxIter) break;
+    if (sx.n == 4) { degenerate = 13; break; }
+  }
+  if (checkSimplex) {
+    vssUpdate(sx);
+    pointOnB = sx.cP2;
+    normalInB = sep;
+    float lenSqr = len2(sep);
+    if ((double)lenSqr < 0.0001) degenerate = 5;
+    if (lenSqr > FLT_EPSILON * FLT_EPSILON) {
+      float rlen = 1.0f / sqrtf(lenSqr);
+      normalInB = normalInB * rlen;
+      distance = (1.0f / rlen);
+      isValid = true;
+    }
+  }
+  bool catchDeg = degenerate && ((double)distance < 0.01);
+  st.isValid = isValid;
+  st.needEpa = (!isValid || catchDeg);
+  st.distance = distance;
+  st.normalInB = normalInB;
+  st.pointOnB = pointOnB;
+  st.offset = offset;
+  st.iters = curIter;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GJK2 + EPA [epa].  All pools live in EpaMem (LDS on the device), indexed by small integers instead of pointers;
+// the recursions of EncloseOrigin and expand are unrolled onto explicit stacks that visit faces in the same order.
+// ---------------------------------------------------------------------------------------------------------------
+#define TOHC_EPA_MAX_VERTICES 64
+#define TOHC_EPA_MAX_FACES 128
+#define TOHC_NIL 255
+
+struct EpaMem {
+  // support vertices: 0..3 = GJK2's m_store, 4..67 = EPA's m_sv_store
+  float svd[4 + TOHC_EPA_MAX_VERTICES][3];
+  float svw[4 + TOHC_EPA_MAX_VERTICES][3];
+  float fn[TOHC_EPA_MAX_FACES][3];
+  float fd[TOHC_EPA_MAX_FACES];
+  uint8_t fc[TOHC_EPA_MAX_FACES][3];
+  uint8_t ff[TOHC_EPA_MAX_FACES][3];
+  uint8_t fe[TOHC_EPA_MAX_FACES][3];
+  uint8_t fl[TOHC_EPA_MAX_FACES][2];
+  uint8_t fpass[TOHC_EPA_MAX_FACES];
+  uint8_t stF[TOHC_EPA_MAX_FACES], stE[TOHC_EPA_MAX_FACES], stS[TOHC_EPA_MAX_FACES];  // expand() stack
+  // GJK2 simplices
+  uint8_t sc[2][4];
+  float sp[2][4];
+  uint8_t freeL[4];
+};
+
+TOHC_DEV V3 ld3(const float *p) { return mk(p[0], p[1], p[2]); }
+TOHC_DEV void st3(float *p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+
+template <int G>
+struct Mink {
+  const Cvx<G> *s0, *s1;
+  M3 toshape1;
+  Xf toshape0;
+  bool margins;
+};
+template <int G>
+TOHC_DEV V3 minkSupport0(const Mink<G> &m, V3 d) { return m.margins ? supWithMarginNV<G>(*m.s0, d) : supNV<G>(*m.s0, d); }
+template <int G>
+TOHC_DEV V3 minkSupport1(const Mink<G> &m, V3 d) {
+  V3 dl = mulMV(m.toshape1, d);
+  V3 s = m.margins ? supWithMarginNV<G>(*m.s1, dl) : supNV<G>(*m.s1, dl);
+  return xfApply(m.toshape0, s);
+}
+template <int G>
+TOHC_DEV V3 minkSupport(const Mink<G> &m, V3 d) { return minkSupport0<G>(m, d) - minkSupport1<G>(m, -d); }
+
+TOHC_DEV float det3(V3 a, V3 b, V3 c) {
+  return (a.y * b.z * c.x + a.z * b.x * c.y - a.x * b.z * c.y - a.y * b.x * c.z + a.x * b.y * c.z - a.z * b.y * c.x);
+}
+TOHC_DEV float projOrigin2(V3 a, V3 b, float *w, unsigned &m) {  // [epa:393-407]
+  V3 d = b - a;
+  float l = len2(d);
+  if (l > 0.0f) {
+    float t = (l > 0 ? -dot(a, d) / l : 0);
+    if (t >= 1) { w[0] = 0; w[1] = 1; m = 2; return len2(b); }
+    else if (t <= 0) { w[0] = 1; w[1] = 0; m = 1; return len2(a); }
+    else { w[0] = 1 - (w[1] = t); m = 3; return len2(a + d * t); }
+  }
+  return -1;
+}
+TOHC_DEV void wset(float *w, unsigned i, float v) {
+#pragma unroll
+  for (unsigned k = 0; k < 4; ++k)
+    if (k == i) w[k] = v;
+}
+TOHC_DEV float projOrigin3(V3 a, V3 b, V3 c, float *w, unsigned &m) {  // [epa:408-453]
+  const V3 vt[3] = {a, b, c};
+  const V3 dl[3] = {a - b, b - c, c - a};
+  V3 n = cross(dl[0], dl[1]);
+  float l = len2(n);
+  if (l > 0.0f) {
+    float mindist = -1;
+    float subw[2] = {0.f, 0.f};
+    unsigned subm = 0;
+#pragma unroll
+    for (unsigned i = 0; i < 3; ++i) {
+      const unsigned j = (i + 1) % 3;
+      if (dot(vt[i], cross(dl[i], n)) > 0) {
+        float subd = projOrigin2(vt[i], vt[j], subw, subm);
+        if ((mindist < 0) || (subd < mindist)) {
+          mindist = subd;
+          m = ((subm & 1) ? 1u << i : 0) + ((subm & 2) ? 1u << j : 0);
+          w[i] = subw[0];
+          w[j] = subw[1];
+          w[(j + 1) % 3] = 0;
+        }
+      }
+    }
+    if (mindist < 0) {
+      float d = dot(a, n);
+      float s = sqrtf(l);
+      V3 p = n * (d / l);
+      mindist = len2(p);
+      m = 7;
+      w[0] = len(cross(dl[1], b - p)) / s;
+      w[1] = len(cross(dl[2], c - p)) / s;
+      w[2] = 1 - (w[0] + w[1]);
+    }
+    return mindist;
+  }
+  return -1;
+}
+TOHC_DEV float projOrigin4(V3 a, V3 b, V3 c, V3 d, float *w, unsigned &m) {  // [epa:454-502]
+  const V3 vt[4] = {a, b, c, d};
+  const V3 dl[3] = {a - d, b - d, c - d};
+  float vl = det3(dl[0], dl[1], dl[2]);
+  bool ng = (vl * dot(a, cross(b - c, a - b))) <= 0;
+  if (ng && (fabsf(vl) > 0.0f)) {
+    float mindist = -1;
+    float subw[3] = {0.f, 0.f, 0.f};
+    unsigned subm = 0;
+#pragma unroll
+    for (unsigned i = 0; i < 3; ++i) {
+      const unsigned j = (i + 1) % 3;
+      float s = vl * dot(d, cross(dl[i], dl[j]));
+      if (s > 0) {
+        float subd = projOrigin3(vt[i], vt[j], d, subw, subm);
+        if ((mindist < 0) || (subd < mindist)) {
+          mindist = subd;
+          m = ((subm & 1) ? 1u << i : 0) + ((subm & 2) ? 1u << j : 0) + ((subm & 4) ? 8 : 0);
+          w[i] = subw[0];
+          w[j] = subw[1];
+          w[(j + 1) % 3] = 0;
+          w[3] = subw[2];
+        }
+      }
+    }
+    if (mindist < 0) {
+      mindist = 0;
+      m = 15;
+      w[0] = det3(c, b, d) / vl;
+      w[1] = det3(a, c, d) / vl;
+      w[2] = det3(b, a, d) / vl;
+      w[3] = 1 - (w[0] + w[1] + w[2]);
+    }
+    return mindist;
+  }
+  return -1;
+}
+
+enum { G2_VALID, G2_INSIDE, G2_FAILED };
+
+template <int G>
+struct Gjk2 {
+  EpaMem *m;
+  Mink<G> shape;
+  V3 ray;
+  float distance;
+  unsigned rank[2];
+  unsigned nfree, current;
+  int status;
+
+  TOHC_DEV void support(V3 d, unsigned sv) {  // getsupport [epa:372-376]
+    V3 dn = vdiv(d, len(d));
+    st3(m->svd[sv], dn);
+    st3(m->svw[sv], minkSupport<G>(shape, dn));
+  }
+  TOHC_DEV V3 W(unsigned s, unsigned i) const { return ld3(m->svw[m->sc[s][i]]); }
+  TOHC_DEV void remove(unsigned s) { m->freeL[nfree++] = m->sc[s][--rank[s]]; }
+  TOHC_DEV void append(unsigned s, V3 v) {
+    m->sp[s][rank[s]] = 0;
+    unsigned sv = m->freeL[--nfree];
+    m->sc[s][rank[s]] = (uint8_t)sv;
+    rank[s]++;
+    support(v, sv);
+  }
+
+  TOHC_DEV int evaluate(const Mink<G> &shapearg, V3 guess) {  // [epa:183-305]
+    unsigned iterations = 0;
+    float sqdist = 0, alpha = 0;
+    V3 lastw[4];
+    unsigned clastw = 0;
+    m->freeL[0] = 0; m->freeL[1] = 1; m->freeL[2] = 2; m->freeL[3] = 3;
+    nfree = 4;
+    current = 0;
+    status = G2_VALID;
+    shape = shapearg;
+    distance = 0;
+    rank[0] = 0; rank[1] = 0;
+    ray = guess;
+    float sqrl = len2(ray);
+    append(0, sqrl > 0 ? -ray : mk(1, 0, 0));
+    m->sp[0][0] = 1;
+    ray = W(0, 0);
+    sqdist = sqrl;
+    lastw[0] = lastw[1] = lastw[2] = lastw[3] = ray;
+    do {
+      const unsigned next = 1 - current;
+      const unsigned cs = current, ns = next;
+      float rl = len(ray);
+      if (rl < 0.0001f) { status = G2_INSIDE; break; }
+      append(cs, -ray);
+      V3 w = W(cs, rank[cs] - 1);
+      bool found = false;
+#pragma unroll
+      for (unsigned i = 0; i < 4; ++i)
+        if (!found && len2(w - lastw[i]) < 0.0001f) found = true;
+      if (found) { remove(current); break; }
+      else {
+        clastw = (clastw + 1) & 3;
+        put(lastw, (int)clastw, w);
+      }
+      float omega = dot(ray, w) / rl;
+      alpha = omega > alpha ? omega : alpha;
+      if (((rl - alpha) - (0.0001f * rl)) <= 0) { remove(current); break; }
+      float weights[4] = {0, 0, 0, 0};
+      unsigned mask = 0;
+      switch (rank[cs]) {
+        case 2: sqdist = projOrigin2(W(cs, 0), W(cs, 1), weights, mask); break;
+        case 3: sqdist = projOrigin3(W(cs, 0), W(cs, 1), W(cs, 2), weights, mask); break;
+        case 4: sqdist = projOrigin4(W(cs, 0), W(cs, 1), W(cs, 2), W(cs, 3), weights, mask); break;
+      }
+      if (sqdist >= 0) {
+        rank[ns] = 0;
+        ray = mk(0, 0, 0);
+        current = next;
+        for (unsigned i = 0, ni = rank[cs]; i < ni; ++i) {
+          float wi = weights[0];
+#pragma unroll
+          for (unsigned k = 1; k < 4; ++k)
+            if (k == i) wi = weights[k];
+          if (mask & (1u << i)) {
+            m->sc[ns][rank[ns]] = m->sc[cs][i];
+            m->sp[ns][rank[ns]] = wi;
+            rank[ns]++;
+            ray = ray + W(cs, i) * wi;
+          } else {
+            m->freeL[nfree++] = m->sc[cs][i];
+          }
+        }
+        if (mask == 15) status = G2_INSIDE;
+      } else {
+        remove(current);
+        break;
+      }
+      status = ((++iterations) < 128) ? status : G2_FAILED;
+    } while (status == G2_VALID);
+    switch (status) {
+      case G2_VALID: distance = len(ray); break;
+      case G2_INSIDE: distance = 0; break;
+      default: break;
+    }
+    return status;
+  }
+
+  // EncloseOrigin [epa:306-370], recursion unrolled: cnt[level] = next candidate to try at that depth
+  TOHC_DEV bool encloseOrigin() {
+    const unsigned s = current;
+    int lvl = 0;
+    int cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
+    for (;;) {
+      const unsigned r = rank[s];
+      if (r == 4) {
+        if (fabsf(det3(W(s, 0) - W(s, 3), W(s, 1) - W(s, 3), W(s, 2) - W(s, 3))) > 0) return true;
+        if (lvl == 0) return false;
+        // return false to the parent: it removes the vertex it appended and tries its next candidate
+        remove(s);
+        --lvl;
+        continue;
+      }
+      int k = lvl == 0 ? cnt0 : lvl == 1 ? cnt1 : lvl == 2 ? cnt2 : cnt3;
+      const int maxc = (r == 3) ? 2 : 6;
+      if (k >= maxc) {
+        if (lvl == 0) return false;
+        remove(s);
+        --lvl;
+        continue;
+      }
+      if (lvl == 0) cnt0 = k + 1; else if (lvl == 1) cnt1 = k + 1; else if (lvl == 2) cnt2 = k + 1; else cnt3 = k + 1;
+      V3 dir;
+      bool ok = true;
+      const int ax = k >> 1;
+      V3 axis = mk(ax == 0 ? 1.0f : 0.0f, ax == 1 ? 1.0f : 0.0f, ax == 2 ? 1.0f : 0.0f);
+      if (r == 1) {
+        dir = axis;
+      } else if (r == 2) {
+        V3 d = W(s, 1) - W(s, 0);
+        dir = cross(d, axis);
+        ok = len2(dir) > 0;
+      } else {
+        dir = cross(W(s, 1) - W(s, 0), W(s, 2) - W(s, 0));
+        ok = len2(dir) > 0;
+      }
+      if (!ok) continue;
+      if (k & 1) dir = -dir;
+      append(s, dir);
+      ++lvl;
+      if (lvl == 1) cnt1 = 0; else if (lvl == 2) cnt2 = 0; else cnt3 = 0;
+    }
+  }
+};
+
+enum { E_VALID, E_TOUCHING, E_DEGENERATED, E_NONCONVEX, E_INVALIDHULL, E_OUTOFFACES, E_OUTOFVERTICES, E_ACCURACY, E_FALLBACK, E_FAILED };
+
+template <int G>
+struct Epa {
+  EpaMem *m;
+  int status;
+  unsigned rrank;
+  unsigned rc[3];
+  float rp[3];
+  V3 normal;
+  float depth;
+  unsigned nextsv;
+  unsigned hullRoot, hullCount, stockRoot, stockCount;
+  // horizon
+  unsigned hcf, hff, hnf;
+
+  TOHC_DEV V3 svW(unsigned sv) const { return ld3(m->svw[sv]); }
+  TOHC_DEV void bind(unsigned fa, unsigned ea, unsigned fb, unsigned eb) {
+    m->fe[fa][ea] = (uint8_t)eb; m->ff[fa][ea] = (uint8_t)fb;
+    m->fe[fb][eb] = (uint8_t)ea; m->ff[fb][eb] = (uint8_t)fa;
+  }
+  TOHC_DEV void append(unsigned &root, unsigned &count, unsigned f) {
+    m->fl[f][0] = TOHC_NIL;
+    m->fl[f][1] = (uint8_t)root;
+    if (root != TOHC_NIL) m->fl[root][0] = (uint8_t)f;
+    root = f;
+    ++count;
+  }
+  TOHC_DEV void removeF(unsigned &root, unsigned &count, unsigned f) {
+    unsigned l1 = m->fl[f][1], l0 = m->fl[f][0];
+    if (l1 != TOHC_NIL) m->fl[l1][0] = (uint8_t)l0;
+    if (l0 != TOHC_NIL) m->fl[l0][1] = (uint8_t)l1;
+    if (f == root) root = l1;
+    --count;
+  }
+  TOHC_DEV void init() {  // [epa:583-593]
+    status = E_FAILED;
+    normal = mk(0, 0, 0);
+    depth = 0;
+    nextsv = 0;
+    hullRoot = TOHC_NIL; hullCount = 0;
+    stockRoot = TOHC_NIL; stockCount = 0;
+    for (unsigned i = 0; i < TOHC_EPA_MAX_FACES; ++i) append(stockRoot, stockCount, TOHC_EPA_MAX_FACES - i - 1);
+  }
+  TOHC_DEV bool getedgedist(V3 fnrm, V3 a, V3 b, float &dist) {  // [epa:698-733]
+    V3 ba = b - a;
+    V3 n_ab = cross(ba, fnrm);
+    float a_dot_nab = dot(a, n_ab);
+    if (a_dot_nab < 0) {
+      float ba_l2 = len2(ba);
+      float a_dot_ba = dot(a, ba);
+      float b_dot_ba = dot(b, ba);
+      if (a_dot_ba > 0) dist = len(a);
+      else if (b_dot_ba < 0) dist = len(b);
+      else {
+        float a_dot_b = dot(a, b);
+        float t = (len2(a) * len2(b) - a_dot_b * a_dot_b) / ba_l2;
+        dist = sqrtf(t > 0.0f ? t : 0.0f);
+      }
+      return true;
+    }
+    return false;
+  }
+  TOHC_DEV unsigned newface(unsigned a, unsigned b, unsigned c, bool forced) {  // [epa:734-778]
+    if (stockRoot != TOHC_NIL) {
+      unsigned face = stockRoot;
+      removeF(stockRoot, stockCount, face);
+      append(hullRoot, hullCount, face);
+      m->fpass[face] = 0;
+      m->fc[face][0] = (uint8_t)a; m->fc[face][1] = (uint8_t)b; m->fc[face][2] = (uint8_t)c;
+      V3 aw = svW(a), bw = svW(b), cw = svW(c);
+      V3 n = cross(bw - aw, cw - aw);
+      float l = len(n);
+      bool v = l > 0.0001f;
+      if (v) {
+        float d;
+        if (!(getedgedist(n, aw, bw, d) || getedgedist(n, bw, cw, d) || getedgedist(n, cw, aw, d))) d = dot(aw, n) / l;
+        n = vdiv(n, l);
+        st3(m->fn[face], n);
+        m->fd[face] = d;
+        if (forced || (d >= -0.00001f)) return face;
+        else status = E_NONCONVEX;
+      } else {
+        st3(m->fn[face], n);
+        status = E_DEGENERATED;
+      }
+      removeF(hullRoot, hullCount, face);
+      append(stockRoot, stockCount, face);
+      return TOHC_NIL;
+    }
+    status = E_OUTOFFACES;
+    return TOHC_NIL;
+  }
+  TOHC_DEV unsigned findbest() {
+    unsigned minf = hullRoot;
+    float mind = m->fd[minf] * m->fd[minf];
+    for (unsigned f = m->fl[minf][1]; f != TOHC_NIL; f = m->fl[f][1]) {
+      float sqd = m->fd[f] * m->fd[f];
+      if (sqd < mind) { minf = f; mind = sqd; }
+    }
+    return minf;
+  }
+  // expand [epa:794-827] on an explicit stack (stage 0: entry, 1: first child returned, 2: second child returned)
+  TOHC_DEV bool expand(unsigned pass, unsigned w, unsigned f0, unsigned e0) {
+    int sp = 0;
+    bool ret = false;
+    m->stF[0] = (uint8_t)f0; m->stE[0] = (uint8_t)e0; m->stS[0] = 0;
+    sp = 1;
+    const V3 ww = svW(w);
+    while (sp > 0) {
+      const unsigned f = m->stF[sp - 1], e = m->stE[sp - 1], stage = m->stS[sp - 1];
+      const unsigned e1 = (e + 1) % 3, e2 = (e + 2) % 3;
+      if (stage == 0) {
+        if (m->fpass[f] != pass) {
+          if ((dot(ld3(m->fn[f]), ww) - m->fd[f]) < -0.00001f) {
+            unsigned nf = newface(m->fc[f][e1], m->fc[f][e], w, false);
+            if (nf != TOHC_NIL) {
+              bind(nf, 0, f, e);
+              if (hcf != TOHC_NIL) bind(hcf, 1, nf, 2); else hff = nf;
+              hcf = nf;
+              ++hnf;
+              ret = true;
+            } else
+              ret = false;
+            --sp;
+          } else {
+            m->fpass[f] = (uint8_t)pass;
+            m->stS[sp - 1] = 1;
+            if (sp >= TOHC_EPA_MAX_FACES) { ret = false; --sp; continue; }  // cannot happen: depth <= hull faces
+            m->stF[sp] = m->ff[f][e1]; m->stE[sp] = m->fe[f][e1]; m->stS[sp] = 0;
+            ++sp;
+          }
+        } else {
+          ret = false;
+          --sp;
+        }
+      } else if (stage == 1) {
+        if (ret) {
+          m->stS[sp - 1] = 2;
+          m->stF[sp] = m->ff[f][e2]; m->stE[sp] = m->fe[f][e2]; m->stS[sp] = 0;
+          ++sp;
+        } else {
+          ret = false;
+          --sp;
+        }
+      } else {
+        if (ret) {
+          removeF(hullRoot, hullCount, f);
+          append(stockRoot, stockCount, f);
+          ret = true;
+        } else
+          ret = false;
+        --sp;
+      }
+    }
+    return ret;
+  }
+
+  TOHC_DEV int evaluate(Gjk2<G> &g, V3 guess) {  // [epa:594-697]
+    const unsigned s = g.current;
+    if ((g.rank[s] > 1) && g.encloseOrigin()) {
+      while (hullRoot != TOHC_NIL) {
+        unsigned f = hullRoot;
+        removeF(hullRoot, hullCount, f);
+        append(stockRoot, stockCount, f);
+      }
+      status = E_VALID;
+      nextsv = 0;
+      unsigned c0 = m->sc[s][0], c1 = m->sc[s][1], c2 = m->sc[s][2], c3 = m->sc[s][3];
+      if (det3(svW(c0) - svW(c3), svW(c1) - svW(c3), svW(c2) - svW(c3)) < 0) {
+        unsigned t = c0; c0 = c1; c1 = t;
+        m->sc[s][0] = (uint8_t)c0; m->sc[s][1] = (uint8_t)c1;
+        float tp = m->sp[s][0]; m->sp[s][0] = m->sp[s][1]; m->sp[s][1] = tp;
+      }
+      unsigned t0 = newface(c0, c1, c2, true);
+      unsigned t1 = newface(c1, c0, c3, true);
+      unsigned t2 = newface(c2, c1, c3, true);
+      unsigned t3 = newface(c0, c2, c3, true);
+      if (hullCount == 4) {
+        unsigned best = findbest();
+        V3 outerN = ld3(m->fn[best]);
+        float outerD = m->fd[best];
+        unsigned oc0 = m->fc[best][0], oc1 = m->fc[best][1], oc2 = m->fc[best][2];
+        unsigned pass = 0, iterations = 0;
+        bind(t0, 0, t1, 0);
+        bind(t0, 1, t2, 0);
+        bind(t0, 2, t3, 0);
+        bind(t1, 1, t3, 2);
+        bind(t1, 2, t2, 1);
+        bind(t2, 2, t3, 1);
+        status = E_VALID;
+        for (; iterations < 255; ++iterations) {
+          if (nextsv < TOHC_EPA_MAX_VERTICES) {
+            hcf = TOHC_NIL; hff = TOHC_NIL; hnf = 0;
+            unsigned w = 4 + nextsv++;
+            bool valid = true;
+            m->fpass[best] = (uint8_t)(++pass);
+            V3 bn = ld3(m->fn[best]);
+            g.support(bn, w);
+            float wdist = dot(bn, svW(w)) - m->fd[best];
+            if (wdist > 0.0001f) {
+              for (unsigned j = 0; (j < 3) && valid; ++j) valid &= expand(pass, w, m->ff[best][j], m->fe[best][j]);
+              if (valid && (hnf >= 3)) {
+                bind(hcf, 1, hff, 2);
+                removeF(hullRoot, hullCount, best);
+                append(stockRoot, stockCount, best);
+                best = findbest();
+                outerN = ld3(m->fn[best]);
+                outerD = m->fd[best];
+                oc0 = m->fc[best][0]; oc1 = m->fc[best][1]; oc2 = m->fc[best][2];
+              } else { status = E_INVALIDHULL; break; }
+            } else { status = E_ACCURACY; break; }
+          } else { status = E_OUTOFVERTICES; break; }
+        }
+        V3 projection = outerN * outerD;
+        normal = outerN;
+        depth = outerD;
+        rrank = 3;
+        rc[0] = oc0; rc[1] = oc1; rc[2] = oc2;
+        rp[0] = len(cross(svW(oc1) - projection, svW(oc2) - projection));
+        rp[1] = len(cross(svW(oc2) - projection, svW(oc0) - projection));
+        rp[2] = len(cross(svW(oc0) - projection, svW(oc1) - projection));
+        float sum = rp[0] + rp[1] + rp[2];
+        rp[0] /= sum; rp[1] /= sum; rp[2] /= sum;
+        return status;
+      }
+    }
+    status = E_FALLBACK;
+    normal = -guess;
+    float nl = len(normal);
+    if (nl > 0) normal = vdiv(normal, nl);
+    else normal = mk(1, 0, 0);
+    depth = 0;
+    rrank = 1;
+    rc[0] = m->sc[s][0];
+    rp[0] = 1;
+    return status;
+  }
+};
+
+template <int G>
+TOHC_DEV void minkInit(Mink<G> &m, const Cvx<G> *s0, const Xf &w0, const Cvx<G> *s1, const Xf &w1, bool margins) {
+  m.s0 = s0; m.s1 = s1;
+  m.toshape1 = transposeTimes(w1.b, w0.b);
+  m.toshape0 = xfInverseTimes(w0, w1);
+  m.margins = margins;
+}
+
+// btGjkEpaPenetrationDepthSolver::calcPenDepth [pds:24-64] = Penetration [epa:903-945], else Distance [epa:865-900]
+template <int G>
+TOHC_DEV bool calcPenDepth(EpaMem *mem, const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &tB, V3 &v, V3 &wA, V3 &wB) {
+  V3 guess = tA.o - tB.o;
+  Mink<G> shape;
+  {
+    minkInit<G>(shape, &A, tA, &B, tB, true);
+    Gjk2<G> g;
+    g.m = mem;
+    int st = g.evaluate(shape, -guess);
+    if (st == G2_INSIDE) {
+      Epa<G> e;
+      e.m = mem;
+      e.init();
+      int es = e.evaluate(g, -guess);
+      if (es != E_FAILED) {
+        V3 w0 = mk(0, 0, 0);
+        for (unsigned i = 0; i < e.rrank; ++i) {
+          unsigned ci = e.rc[0];
+          float pi = e.rp[0];
+          if (i == 1) { ci = e.rc[1]; pi = e.rp[1]; }
+          if (i == 2) { ci = e.rc[2]; pi = e.rp[2]; }
+          w0 = w0 + minkSupport0<G>(shape, ld3(mem->svd[ci])) * pi;
+        }
+        wA = xfApply(tA, w0);
+        wB = xfApply(tA, w0 - e.normal * e.depth);
+        v = -e.normal;
+        return true;
+      }
+    }
+  }
+  {
+    minkInit<G>(shape, &A, tA, &B, tB, false);
+    Gjk2<G> g;
+    g.m = mem;
+    int st = g.evaluate(shape, guess);
+    if (st == G2_VALID) {
+      V3 a = mk(0, 0, 0), b = mk(0, 0, 0);
+      const unsigned s = g.current;
+      for (unsigned i = 0; i < g.rank[s]; ++i) {
+        float p = mem->sp[s][i];
+        V3 d = ld3(mem->svd[mem->sc[s][i]]);
+        a = a + minkSupport0<G>(shape, d) * p;
+        b = b + minkSupport1<G>(shape, -d) * p;
+      }
+      wA = xfApply(tA, a);
+      wB = xfApply(tA, b);
+      V3 nrm = a - b;
+      float dist = len(nrm);
+      v = vdiv(nrm, dist > 0.0001f ? dist : 1);
+      return false;
+    }
+  }
+  return false;
+}
+
+// second half of getClosestPointsNonVirtual [gjk:334-449]: penetration / degenerate handling and the output filter
+struct PairOut {
+  bool valid;
+  V3 normalOnB, pointOnB;
+  float distance;
+};
+
+template <int G>
+TOHC_DEV void gjkFinishEpa(EpaMem *mem, const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &tB, GjkState &st) {
+  Xf lA = tA, lB = tB;
+  lA.o = lA.o - st.offset;
+  lB.o = lB.o - st.offset;
+  V3 tmpA = mk(0, 0, 0), tmpB = mk(0, 0, 0), sep = mk(0, 0, 0);
+  bool isValid2 = calcPenDepth<G>(mem, A, B, lA, lB, sep, tmpA, tmpB);
+  if (isValid2) {
+    V3 tmpN = tmpB - tmpA;
+    float lenSqr = len2(tmpN);
+    if (lenSqr <= (FLT_EPSILON * FLT_EPSILON)) { tmpN = sep; lenSqr = len2(sep); }
+    if (lenSqr > (FLT_EPSILON * FLT_EPSILON)) {
+      tmpN = vdiv(tmpN, sqrtf(lenSqr));
+      float distance2 = -len(tmpA - tmpB);
+      if (!st.isValid || (distance2 < st.distance)) {
+        st.distance = distance2; st.pointOnB = tmpB; st.normalInB = tmpN; st.isValid = true;
+      }
+    }
+  } else {
+    if (len2(sep) > 0.0f) {
+      float distance2 = len(tmpA - tmpB);
+      if (!st.isValid || (distance2 < st.distance)) {
+        st.distance = distance2;
+        st.pointOnB = tmpB;
+        st.normalInB = vdiv(sep, len(sep));
+        st.isValid = true;
+      }
+    }
+  }
+}
+
+TOHC_DEV void gjkOutput(const GjkState &st, float maxDist2, PairOut &o) {
+  o.valid = false;
+  if (st.isValid && ((st.distance < 0) || (st.distance * st.distance < maxDist2))) {
+    o.valid = true;
+    o.normalOnB = st.normalInB;
+    o.pointOnB = st.pointOnB + st.offset;
+    o.distance = st.distance;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GetAverageSupport [bcc:98-131] for a box (8 vertices, btBoxShape::getVertex) or a hull.  The reference sums the
+// vertices serially in index order with a running maximum, which is order dependent; the group replays exactly that
+// scan: vertex i is broadcast from its owning lane in index order (only for kept contacts, so the cost is small).
+// ---------------------------------------------------------------------------------------------------------------
+template <int G>
+TOHC_DEV void averageSupport(const Cvx<G> &c, V3 nl, float &outsup, V3 &outpt) {
+  V3 sum = mk(0, 0, 0);
+  float cnt = 0, maxS = -1000;
+  const float EPS = 1e-3f;
+  const int np = c.kind == KIND_BOX ? 8 : c.n;
+  for (int i = 0; i < np; ++i) {
+    V3 pt;
+    if (c.kind == KIND_BOX) {
+      V3 he = c.dims;
+      pt = mk(he.x * (1 - (i & 1)) - he.x * (i & 1), he.y * (1 - ((i & 2) >> 1)) - he.y * ((i & 2) >> 1),
+              he.z * (1 - ((i & 4) >> 2)) - he.z * ((i & 4) >> 2));
+    } else {
+      const int slot = i / G, src = i % G;
+      float sx = c.x[0], sy = c.y[0], sz = c.z[0];
+#pragma unroll
+      for (int s = 1; s < Cvx<G>::VPL; ++s)
+        if (s == slot) { sx = c.x[s]; sy = c.y[s]; sz = c.z[s]; }
+      pt = mk(Grp<G>::bcast(sx, src), Grp<G>::bcast(sy, src), Grp<G>::bcast(sz, src));
+    }
+    float sup = dot(pt, nl);
+    if (sup > maxS + EPS) { cnt = 1; sum = pt; maxS = sup; }
+    else if (sup < maxS - EPS) {}
+    else { cnt += 1; sum = sum + pt; }
+  }
+  outsup = maxS;
+  outpt = vdiv(sum, cnt);
+}
+
+// CastCollisionCollector::addSingleResult [bcc:894-972].  In: the contact as Bullet reported it (A/B = GJK roles,
+// castFirst <=> the swept shape was GJK's A).  Out: after the swap the swept link is B.
+struct CastOut {
+  int cctype;
+  float time;
+  V3 ptB, ptB1;
+  bool between;
+};
+template <int G>
+TOHC_DEV void castClassify(const Cvx<G> &cq, const Xf &tf0, const Xf &tw1, V3 nW, V3 ptA, V3 ptB, bool castFirst, CastOut &o) {
+  V3 nFromCast = nW * (-(float)(castFirst ? 1 : -1));
+  V3 nl0 = mulVM(nFromCast, tf0.b);
+  V3 nl1 = mulVM(nFromCast, tw1.b);
+  V3 pl0, pl1;
+  float ls0, ls1;
+  averageSupport<G>(cq, nl0, ls0, pl0);
+  V3 pw0 = xfApply(tf0, pl0);
+  averageSupport<G>(cq, nl1, ls1, pl1);
+  V3 pw1 = xfApply(tw1, pl1);
+  float sup0 = dot(nFromCast, pw0);
+  float sup1 = dot(nFromCast, pw1);
+  o.between = false;
+  if (sup0 - sup1 > .01f) { o.time = 0; o.cctype = 1; }
+  else if (sup1 - sup0 > .01f) { o.time = 1; o.cctype = 2; }
+  else {
+    V3 ptOnCast = castFirst ? ptA : ptB;
+    float l0c = len(ptOnCast - pw0), l1c = len(ptOnCast - pw1);
+    o.ptB = pw0;
+    o.ptB1 = pw1;
+    o.cctype = 3;
+    o.between = true;
+    if (l0c + l1c < .001f) o.time = .5f;
+    else o.time = l0c / (l0c + l1c);
+  }
+}
+
+}  // namespace tohc

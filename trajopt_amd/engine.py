@@ -1,0 +1,203 @@
+"""ctypes binding of libtrajopt_hipcc.so (include/trajopt_hipcc.h) -- the Python-side test and bench harness.
+
+Everything goes through the C-ABI; there is no CPU fallback: if the library or a GPU is missing, construction
+raises.  The host-side mirror of trajopt::CollisionChecker built on this lives in collision_checker.py.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtrajopt_hipcc.so")
+
+RECORD_DTYPE = np.dtype([
+    ("problem", "i4"), ("t", "i4"), ("idA", "i4"), ("childA", "i4"), ("idB", "i4"), ("childB", "i4"),
+    ("cctype", "i4"), ("time", "f4"), ("dist", "f8"), ("n", "f8", 3), ("ptA", "f8", 3), ("ptB", "f8", 3),
+    ("ptB1", "f8", 3), ("const0", "f8"), ("const1", "f8")], align=True)
+assert RECORD_DTYPE.itemsize == 152
+
+
+class Counters(C.Structure):
+    _fields_ = [("aabb_tests", C.c_int64), ("pair_evals", C.c_int64), ("epa_evals", C.c_int64),
+                ("contacts", C.c_int64), ("ms_last_call", C.c_double)]
+
+
+class EngineError(RuntimeError):
+    """The reference throws std::runtime_error (collision_checker.hpp:57-62); the C-ABI returns codes."""
+
+    def __init__(self, code, msg):
+        super().__init__("tohc error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+_i32p, _f32p, _f64p, _u8p = (C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_uint8))
+
+SYMBOLS = {
+    "tohc_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "tohc_destroy": (None, [C.c_void_p]),
+    "tohc_last_error": (C.c_char_p, [C.c_void_p]),
+    "tohc_upload_scene": (C.c_int, [C.c_void_p, C.c_int, _i32p, _f32p, _i32p, _i32p, C.c_int, _f32p, _f32p, _f32p, C.c_int,
+                                    _i32p, _f64p, C.c_int, _i32p, _i32p, _i32p, _i32p, _f64p]),
+    "tohc_upload_robot": (C.c_int, [C.c_void_p, C.c_int, _i32p, _i32p, _f64p, _f64p, _i32p, _f64p, _f64p, _i32p, C.c_int,
+                                    _f64p, _f64p, C.c_int, _i32p, C.c_int, _f64p]),
+    "tohc_set_allowed_matrix": (C.c_int, [C.c_void_p, C.c_int, _u8p]),
+    "tohc_set_contact_distance": (C.c_int, [C.c_void_p, C.c_float]),
+    "tohc_get_contact_distance": (C.c_double, [C.c_void_p]),
+    "tohc_links_vs_all_batch": (C.c_int, [C.c_void_p, _f64p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                          C.POINTER(_f64p), C.POINTER(C.c_int)]),
+    "tohc_cast_vs_all_batch": (C.c_int, [C.c_void_p, _f64p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                         C.POINTER(_f64p), C.POINTER(C.c_int)]),
+    "tohc_links_vs_all_poses": (C.c_int, [C.c_void_p, _f64p, C.c_int, _i32p, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_int)]),
+    "tohc_cast_vs_all_poses": (C.c_int, [C.c_void_p, _f64p, _f64p, C.c_int, _i32p, C.c_int, C.POINTER(C.c_void_p),
+                                         C.POINTER(C.c_int)]),
+    "tohc_forward_kinematics": (C.c_int, [C.c_void_p, _f64p, C.c_int, _f64p]),
+    "tohc_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
+    "tohc_set_capacity": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64]),
+}
+
+
+def load_library():
+    """Load the C-ABI library and declare every symbol of include/trajopt_hipcc.h (raises if one is missing)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(-2, "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(lib, name)
+            f.restype, f.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class Engine:
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        rc = self.lib.tohc_create(C.byref(self.h), int(device))
+        if rc != 0:
+            self.h = None
+            raise EngineError(rc, "tohc_create failed (no HIP device? the engine has no CPU fallback)")
+        self.K = 0
+        self.n_objects = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tohc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise EngineError(rc, self.lib.tohc_last_error(self.h).decode())
+
+    # -- uploads ---------------------------------------------------------------------------------------
+    def upload_scene(self, scene, static_T):
+        a = scene.arrays
+        static_T = np.ascontiguousarray(static_T, np.float64).reshape(-1, 7)
+        assert len(static_T) == len(a["obj_off"])
+        v = np.ascontiguousarray(a["verts"], np.float32).reshape(-1, 3)
+        nv = int(a["vcnt"].sum())
+        vx, vy, vz = (np.ascontiguousarray(v[:, i]) for i in range(3))
+        self._chk(self.lib.tohc_upload_scene(
+            self.h, len(a["kind"]), _p(a["kind"], C.c_int32), _p(a["param"], C.c_float), _p(a["voff"], C.c_int32),
+            _p(a["vcnt"], C.c_int32), nv, _p(vx, C.c_float), _p(vy, C.c_float), _p(vz, C.c_float),
+            len(a["child_shape"]), _p(a["child_shape"], C.c_int32), _p(a["child_T"], C.c_double), len(a["obj_off"]),
+            _p(a["obj_off"], C.c_int32), _p(a["obj_cnt"], C.c_int32), _p(a["obj_compound"], C.c_int32),
+            _p(a["obj_group"], C.c_int32), _p(static_T, C.c_double)))
+        self.n_objects = len(a["obj_off"])
+
+    def upload_robot(self, robot):
+        a = robot.arrays
+        self._chk(self.lib.tohc_upload_robot(
+            self.h, robot.n_links, _p(a["parent"], C.c_int32), _p(a["jtype"], C.c_int32), _p(a["T_origin"], C.c_double),
+            _p(a["axis"], C.c_double), _p(a["dof"], C.c_int32), _p(a["mult"], C.c_double), _p(a["offs"], C.c_double),
+            _p(a["link_obj"], C.c_int32), robot.n_dof, _p(a["q_robot"], C.c_double), _p(a["base_T"], C.c_double),
+            len(robot.joint_inds), _p(a["joint_inds"], C.c_int32), robot.affine, _p(a["rot_axis"], C.c_double)))
+        self.K = robot.K
+        self.n_links = robot.n_links
+
+    def set_allowed_matrix(self, m):
+        m = np.ascontiguousarray(m, np.uint8)
+        self._chk(self.lib.tohc_set_allowed_matrix(self.h, m.shape[0], _p(m, C.c_uint8)))
+
+    def set_contact_distance(self, d):
+        self._chk(self.lib.tohc_set_contact_distance(self.h, float(d)))
+
+    def get_contact_distance(self):
+        return self.lib.tohc_get_contact_distance(self.h)
+
+    def set_capacity(self, max_pairs, max_records):
+        self._chk(self.lib.tohc_set_capacity(self.h, int(max_pairs), int(max_records)))
+
+    # -- queries ---------------------------------------------------------------------------------------
+    def _collect(self, rec_p, grad_p, n, K, copy):
+        n = n.value
+        if n == 0:
+            return np.zeros(0, RECORD_DTYPE), np.zeros((0, 2, max(K, 1)))
+        recs = np.frombuffer((C.c_char * (n * 152)).from_address(rec_p.value), dtype=RECORD_DTYPE, count=n)
+        grads = None
+        if grad_p is not None and bool(grad_p):
+            grads = np.ctypeslib.as_array(grad_p, shape=(n, 2, K))
+        if copy:
+            recs = recs.copy()
+            grads = None if grads is None else grads.copy()
+        return recs, grads
+
+    def links_vs_all_batch(self, dofs, B, T, filter_mask=-1, want_jacobians=True, copy=True):
+        dofs = np.ascontiguousarray(dofs, np.float64)
+        assert dofs.size == B * T * self.K
+        rec, g, n = C.c_void_p(), _f64p(), C.c_int()
+        self._chk(self.lib.tohc_links_vs_all_batch(self.h, _p(dofs, C.c_double), B, T, int(filter_mask), int(want_jacobians),
+                                                   C.byref(rec), C.byref(g), C.byref(n)))
+        return self._collect(rec, g, n, self.K, copy)
+
+    def cast_vs_all_batch(self, dofs, B, T, gap=1, want_jacobians=True, copy=True):
+        dofs = np.ascontiguousarray(dofs, np.float64)
+        assert dofs.size == B * T * self.K
+        rec, g, n = C.c_void_p(), _f64p(), C.c_int()
+        self._chk(self.lib.tohc_cast_vs_all_batch(self.h, _p(dofs, C.c_double), B, T, int(gap), int(want_jacobians),
+                                                  C.byref(rec), C.byref(g), C.byref(n)))
+        return self._collect(rec, g, n, self.K, copy)
+
+    def links_vs_all_poses(self, obj_T, query, filter_mask=-1):
+        obj_T = np.ascontiguousarray(obj_T, np.float64).reshape(-1, self.n_objects, 7)
+        q = np.ascontiguousarray(query, np.int32)
+        rec, n = C.c_void_p(), C.c_int()
+        self._chk(self.lib.tohc_links_vs_all_poses(self.h, _p(obj_T, C.c_double), obj_T.shape[0], _p(q, C.c_int32), len(q),
+                                                   int(filter_mask), C.byref(rec), C.byref(n)))
+        return self._collect(rec, None, n, 1, True)[0]
+
+    def cast_vs_all_poses(self, obj_T, query, T1):
+        obj_T = np.ascontiguousarray(obj_T, np.float64).reshape(-1, self.n_objects, 7)
+        q = np.ascontiguousarray(query, np.int32)
+        T1 = np.ascontiguousarray(T1, np.float64).reshape(obj_T.shape[0], len(q), 7)
+        rec, n = C.c_void_p(), C.c_int()
+        self._chk(self.lib.tohc_cast_vs_all_poses(self.h, _p(obj_T, C.c_double), _p(T1, C.c_double), obj_T.shape[0],
+                                                  _p(q, C.c_int32), len(q), C.byref(rec), C.byref(n)))
+        return self._collect(rec, None, n, 1, True)[0]
+
+    def forward_kinematics(self, dofs):
+        dofs = np.ascontiguousarray(dofs, np.float64).reshape(-1, self.K)
+        out = np.zeros((len(dofs), self.n_links, 7))
+        self._chk(self.lib.tohc_forward_kinematics(self.h, _p(dofs, C.c_double), len(dofs), _p(out, C.c_double)))
+        return out
+
+    def counters(self):
+        c = Counters()
+        self._chk(self.lib.tohc_get_counters(self.h, C.byref(c)))
+        return dict(aabb_tests=c.aabb_tests, pair_evals=c.pair_evals, epa_evals=c.epa_evals, contacts=c.contacts,
+                    ms_last_call=c.ms_last_call)
