@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- collision-cost linearization throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (config.workload): BASELINE.json configs[3] -- full-body PR2-like robot (K=18), 100 timesteps, against a
+4096-hull convex soup, d = 0.09 -- batched as `problems_per_gpu` independent multi-start trajectories per GPU
+(configs[4]'s sharding: problems are partitioned over ranks, no data-path collective).  One STEP = one SQP
+linearization of every problem on the rank: the discrete collision cost (100 terms, self collision included) and the
+cast collision cost (99 swept terms), contacts + gradient rows, into one device slab -- FK, broadphase, GJK, EPA and
+the Jacobian epilogue all inside the timed region; the DOF vectors are already resident in HBM (tohc_stage_dofs).
+`value` = pair-evals of all ranks / max-over-ranks wall time.  The PCIe-inclusive API rate (stage + enqueue + fetch to
+pinned host memory, canonical order) is reported beside it as `api_value`; it is never `value`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_world(rank, problems, T=100):
+    from trajopt_amd import collision_checker as CC, synth
+    s, rb, static_T, d = synth.config_fullbody_soup()
+    cc = CC.HIPCollisionChecker(s, static_T, None, device=rank_device(rank))
+    cc.SetRobot(rb)                       # uploads + IgnoreZeroStateSelfCollisions, like the reference's AddKinBody path
+    cc.SetContactDistance(d)
+    cc.eng.set_capacity(1 << 23, 1 << 21)
+    rng = np.random.default_rng(1000 + rank)
+    dofs = np.stack([synth.fullbody_trajectory(rb, rng, T) for _ in range(problems)])
+    return s, rb, static_T, d, cc, dofs
+
+
+def rank_device(rank):
+    return int(os.environ.get("LOCAL_RANK", rank))
+
+
+def cpu_baseline(s, rb, static_T, d, allowed, traj, budget_s=12.0):
+    """The CPU path on ONE host core, on a bounded sample of the same workload: timesteps of problem 0 taken with a
+    stride until ~budget_s of work.  kind=reference: the reference's own vendored Bullet (oracle/_ref) doing
+    LinksVsAll + CastVsAll on poses from the oracle's FK (FK / Jacobian time NOT charged to it);
+    kind=port: the C restatement doing the full linearization."""
+    from oracle import bindings as B
+    T = len(traj)
+    out = {}
+    wo = B.oracle_world(s, cap=1 << 18)
+    wo.set_contact_distance(d)
+    wo.set_allowed(allowed)
+    # port
+    t0 = time.perf_counter()
+    pe0 = wo.counter(0)
+    used = 0
+    for t in list(range(0, T - 1, 7)) + [t for t in range(T - 1) if t % 7]:
+        wo.linearize(rb, static_T, traj[t:t + 1])
+        wo.linearize(rb, static_T, traj[t:t + 2], cast=True)
+        used += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    out["port"] = dict(value=(wo.counter(0) - pe0) / dt, seconds=dt, timesteps=used)
+    if B.ref_available():
+        wr = B.ref_world(s, cap=1 << 18)
+        wr.set_contact_distance(d)
+        wr.set_allowed(allowed)
+        lib = wr.lib
+        objs, links = rb.affected_links()
+        link_obj = np.array(rb.link_obj)
+        have = link_obj >= 0
+
+        def poses(q):
+            Tall = static_T.copy()
+            fk = B.oracle_fk(rb, q)
+            Tall[link_obj[have]] = fk[have]
+            return Tall, fk
+
+        g0 = lib.ref_gjk_checks()
+        tsum, used = 0.0, 0
+        for t in list(range(0, T - 1, 7)) + [t for t in range(T - 1) if t % 7]:
+            P0, fk0 = poses(traj[t])
+            _, fk1 = poses(traj[t + 1])
+            t0 = time.perf_counter()
+            wr.links_vs_all(P0, objs)
+            wr.cast_vs_all(P0, objs, fk0[links], fk1[links])
+            tsum += time.perf_counter() - t0
+            used += 1
+            if tsum > budget_s:
+                break
+        out["reference"] = dict(value=(lib.ref_gjk_checks() - g0) / tsum, seconds=tsum, timesteps=used)
+        wr.close()
+    wo.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--problems-per-gpu", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(rank_device(rank))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", rank_device(rank)))
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the engine has no CPU fallback"
+
+    P, T = args.problems_per_gpu, 100
+    s, rb, static_T, d, cc, dofs = build_world(rank, P, T)
+    eng = cc.eng
+
+    def step():
+        eng.enqueue_links_vs_all(-1, True, append=False)
+        eng.enqueue_cast_vs_all(1, True, append=True)
+        eng.sync()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.stage_dofs(dofs, P, T)
+    for _ in range(args.warmup):
+        step()
+    c0 = eng.counters()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    c1 = eng.counters()
+    rec, grads = eng.fetch()
+
+    pair_evals = c1["cum_pair_evals"] - c0["cum_pair_evals"]
+    tot = torch.tensor([dt, float(pair_evals)], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        tmax = tot[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        psum = tot[1:].clone()
+        dist.all_reduce(psum, op=dist.ReduceOp.SUM)
+        dt_max, pairs_all = float(tmax.item()), float(psum.item())
+    else:
+        dt_max, pairs_all = dt, float(pair_evals)
+
+    # PCIe-inclusive API rate on rank 0's data (never `value`)
+    api = None
+    if rank == 0:
+        ta = time.perf_counter()
+        n_api = 3
+        pe = 0
+        for _ in range(n_api):
+            eng.stage_dofs(dofs, P, T)
+            eng.enqueue_links_vs_all(-1, True, append=False)
+            eng.enqueue_cast_vs_all(1, True, append=True)
+            eng.fetch(copy=False)
+            pe += eng.counters()["pair_evals"]
+        api = pe / (time.perf_counter() - ta)
+        # latency of ONE problem's linearization, results in host memory (north-star: < 1 ms)
+        eng.stage_dofs(dofs[:1], 1, T)
+        lat = []
+        for _ in range(10):
+            tl = time.perf_counter()
+            eng.enqueue_links_vs_all(-1, True, append=False)
+            eng.enqueue_cast_vs_all(1, True, append=True)
+            eng.fetch(copy=False)
+            lat.append((time.perf_counter() - tl) * 1e3)
+        lat_ms = float(np.median(lat))
+        lat_dev_ms = eng.counters()["ms_last_call"]
+
+    if rank == 0:
+        launches = c1["cum_launches"] - c0["cum_launches"]
+        ms = {k: (c1["cum_ms_" + k] - c0["cum_ms_" + k]) / max(launches, 1) for k in ("fk", "children", "broadphase", "gjk", "epa")}
+        # roofline of the dominant kernel (k_gjk): algorithmic bytes per pair-eval (SURVEY.md 8d / DESIGN.md):
+        #   12*(nA+nB) vertices + 96 two fp32 3x4 transforms + [152 + 16*K if a record is written]
+        a = s.arrays
+        child_v = np.where(a["kind"][a["child_shape"]] == 1, a["vcnt"][a["child_shape"]], 8)
+        objs, _ = rb.affected_links()
+        qch = np.concatenate([np.arange(a["obj_off"][o], a["obj_off"][o] + a["obj_cnt"][o]) for o in objs])
+        n_q = float(child_v[qch].mean())
+        n_x = float(child_v.mean())       # dominated by the 4096 soup children
+        per_launch_pairs = pair_evals / max(launches, 1)
+        per_launch_contacts = c1["contacts"] / 2.0   # slab of one step holds both launches
+        bytes_per_launch = per_launch_pairs * (12.0 * (n_q + n_x) + 96.0) + per_launch_contacts * (152.0 + 16.0 * rb.K)
+        achieved = bytes_per_launch / (ms["gjk"] * 1e-3) / 1e9 if ms["gjk"] > 0 else 0.0
+        out = {
+            "metric": "signed-distance+Jacobian pair-evals/s (node)",
+            "value": pairs_all / dt_max,
+            "unit": "pair-evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[3]: full-body PR2-like (K=18) x 100 timesteps vs 4096-hull convex soup, d=0.09, "
+                                   "discrete+cast collision costs with gradient rows; %d independent multi-start problems per GPU" % P,
+                       "problems_per_gpu": P, "timesteps": T, "K": rb.K, "parallelism": "problems sharded over %d GPU(s), no collective" % world},
+            "pair_evals_per_step_per_gpu": pair_evals / args.steps,
+            "contacts_per_step_per_gpu": int(c1["contacts"]),
+            "ms_per_sqp_linearization_single_problem_host_delivered": lat_ms,
+            "ms_per_sqp_linearization_single_problem_device": lat_dev_ms,
+            "api_value": api,
+            "kernel_ms_per_launch": ms,
+            "roofline": {"bound": "hbm", "kernel": "k_gjk", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "note": "VALU/cross-lane bound iterative fp32 kernel; bytes are compulsory only (SURVEY 8d)"},
+        }
+        if not args.no_cpu_baseline:
+            cb = cpu_baseline(s, rb, static_T, d, cc.allowed, dofs[0])
+            kind = "reference" if "reference" in cb else "port"
+            out["cpu_baseline"] = {"value": cb[kind]["value"], "unit": "pair-evals/s", "cores": 1, "kind": kind,
+                                   "sample": "problem 0, %d of its 100 timesteps (%.1f s of CPU work): discrete LinksVsAll + CastVsAll on one core"
+                                             % (cb[kind]["timesteps"], cb[kind]["seconds"]),
+                                   "port_value": cb["port"]["value"]}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    cc.eng.close()
+
+
+if __name__ == "__main__":
+    main()

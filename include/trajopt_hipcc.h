@@ -61,11 +61,15 @@ typedef struct tohc_record {
 } tohc_record;
 
 typedef struct tohc_counters {
+  /* since the last sync (all enqueues it covered) */
   int64_t aabb_tests;   /* (timestep, query child, other child) tuples examined by the broadphase    */
   int64_t pair_evals;   /* tuples that survived the cull and got a GJK evaluation                     */
   int64_t epa_evals;    /* of those, how many went through GJK2+EPA                                   */
-  int64_t contacts;     /* records written                                                            */
-  double ms_last_call;  /* device time of the last batch call (HIP events on the engine's stream)     */
+  int64_t contacts;     /* records in the slab                                                        */
+  double ms_last_call;  /* device time of those enqueues (HIP events on the engine's stream)          */
+  /* cumulative since tohc_create; per-kernel device time from HIP events around every launch         */
+  int64_t cum_aabb_tests, cum_pair_evals, cum_epa_evals, cum_launches;
+  double cum_ms_fk, cum_ms_children, cum_ms_broadphase, cum_ms_gjk, cum_ms_epa;
 } tohc_counters;
 
 /* replaces CreateCollisionChecker(env)                       src/trajopt/bullet_collision_checker.cpp:1036-1039 */
@@ -116,6 +120,18 @@ int tohc_links_vs_all_batch(tohc_engine *e, const double *dofs, int B, int T, in
  * one swept check per (problem, t, t+gap), t in [0, T-gap); record.t is the first timestep of the pair. */
 int tohc_cast_vs_all_batch(tohc_engine *e, const double *dofs, int B, int T, int gap, int want_jacobians,
                            const tohc_record **records, const double **grads, int *n_records);
+
+/* The batch calls above are stage -> enqueue -> fetch in a row.  Callers that keep inputs resident (an SQP loop that
+ * re-linearizes, the benchmark) use the pieces: stage copies the DOF vectors to HBM; enqueue runs FK, broadphase and
+ * narrowphase asynchronously on the engine's stream and leaves the slab on the device (append != 0 adds to the slab
+ * of the previous enqueue, so one slab can carry the discrete and the cast cost of one SQP linearization); fetch
+ * waits, copies the slab to the pinned host buffer and puts it in canonical order.  No counterpart in the reference
+ * (its checker is synchronous, one timestep per call: SURVEY.md F6). */
+int tohc_stage_dofs(tohc_engine *e, const double *dofs, int B, int T);
+int tohc_enqueue_links_vs_all(tohc_engine *e, int filter_mask, int want_jacobians, int append);
+int tohc_enqueue_cast_vs_all(tohc_engine *e, int gap, int want_jacobians, int append);
+int tohc_sync(tohc_engine *e);
+int tohc_fetch(tohc_engine *e, const tohc_record **records, const double **grads, int *n_records);
 
 /* replaces LinksVsAll / CastVsAll on explicit poses (no robot model needed): the reference reads poses from the
  * OpenRAVE environment at call time (UpdateBulletFromRave, bullet_collision_checker.cpp:648-653).

@@ -1,0 +1,265 @@
+"""GPU suite (-m gpu): the HIP engine, called through the C-ABI, against the CPU oracle and the golden fixtures.
+
+Bar (BASELINE.json north_star): contact pair set bit-exact; distances / normals / points compared BIT-FOR-BIT with the
+oracle (stricter than the 1e-5 m / 1e-4 rad asked); Jacobian rows within 1e-5 relative (FK runs on the device with
+the device's sin/cos).  Full-size configs are checked through size-independent properties.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bindings as B
+from trajopt_amd import model as M, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "random_scene_*.npz")))
+
+
+@pytest.fixture(scope="module")
+def eng(built):
+    from trajopt_amd import engine
+    assert os.path.exists(engine.LIB_PATH), "HIP extension missing: the product path must not fall back"
+    e = engine.Engine(0)
+    yield e
+    e.close()
+
+
+def T(x, y=0, z=0):
+    return (1, 0, 0, 0, x, y, z)
+
+
+def test_reference_box_distance_counts(eng):
+    # collision-checker-unit.cpp:48-87 through the C-ABI (BodyVsAll(box0))
+    s = M.Scene()
+    b = s.add_box(.5, .5, .5)
+    o0 = s.add_object([(b, M.IDENT7)], M.GROUP_KINBODY)
+    s.add_object([(b, M.IDENT7)], M.GROUP_KINBODY)
+    s.finalize()
+    eng.upload_scene(s, [T(0), T(0)])
+    for d, x, n in [(0, .9, 1), (0, 1.1, 0), (.04, 1.1, 0), (.1, 1.09, 1), (.2, 1.1, 1)]:
+        eng.set_contact_distance(d)
+        assert eng.get_contact_distance() == np.float32(d)
+        rec = eng.links_vs_all_poses([T(0), T(x)], [o0])
+        assert len(rec) == n, (d, x)
+    eng.set_contact_distance(0)
+    rec = eng.links_vs_all_poses([T(0), T(.9)], [o0])
+    assert np.float32(rec[0]["dist"]) == np.float32(-0.0577350222)  # SURVEY.md 8c known answer (EPA, diagonal normal)
+
+
+def test_reference_cast_known_answers(eng):
+    # collision-checker-unit.cpp:130-150
+    s = M.Scene()
+    b = s.add_box(.5, .5, .5)
+    s.add_object([(b, M.IDENT7)], M.GROUP_KINBODY)
+    bot = s.add_object([(b, M.IDENT7)], M.GROUP_ROBOT)
+    s.finalize()
+    eng.upload_scene(s, [T(0), T(0)])
+    eng.set_contact_distance(0.05)
+    cases = [((-1.9, 0), (0, 1.9), (-1 / np.sqrt(2), 1 / np.sqrt(2), 0), .5, 1e-1),
+             ((0, .9), (0, 2), (0, 1, 0), 0, 1e-6), ((0, 2), (0, .9), (0, 1, 0), 1, 1e-6)]
+    for a, b_, nrm, time, ttol in cases:
+        rec = eng.cast_vs_all_poses([T(0), T(*a)], [bot], [T(*b_)])
+        assert len(rec) == 1
+        robot_normal = (1 if rec[0]["idA"] == bot else -1) * rec[0]["n"]
+        assert np.allclose(robot_normal, nrm, atol=1e-4) and abs(rec[0]["time"] - time) <= ttol
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_golden_fixtures_bit_exact(eng, path):
+    z = np.load(path, allow_pickle=False)
+    s = M.scene_from_arrays({k[6:]: z[k] for k in z.files if k.startswith("scene_")})
+    eng.upload_scene(s, z["objT"])
+    robot = z["robot"]
+    for i, d in enumerate(z["dists"]):
+        eng.set_contact_distance(float(d))
+        rec = eng.links_vs_all_poses(z["objT"], robot)
+        util.assert_same_contacts(util.records_to_contacts(rec), z["disc_%d" % i], "disc d=%g" % d)
+        rec = eng.cast_vs_all_poses(z["objT"], robot, z["T1"])
+        util.assert_same_contacts(util.records_to_contacts(rec), z["cast_%d" % i], "cast d=%g" % d)
+
+
+@pytest.mark.parametrize("seed,spread", [(200, 0.6), (201, 0.3), (202, 0.25), (203, 0.45), (204, 0.3), (205, 1.0)])
+def test_random_scenes_vs_oracle_poses_api(eng, seed, spread):
+    """Several pose sets per call (the batch axis), discrete and cast, dense (EPA heavy) and sparse."""
+    rng = np.random.default_rng(seed)
+    s, objT, robot = synth.random_scene(rng, spread=spread, n_static=8, n_robot=5)
+    nsets = 4
+    sets = np.stack([objT] + [np.array([synth.random_T7(rng, -spread, spread) for _ in range(len(objT))]) for _ in range(nsets - 1)])
+    T1 = sets[:, robot].copy()
+    T1[..., 4:] += rng.normal(size=T1[..., 4:].shape) * 0.15
+    T1[..., :4] += rng.normal(size=T1[..., :4].shape) * 0.2
+    T1[..., :4] /= np.linalg.norm(T1[..., :4], axis=-1, keepdims=True)
+    eng.upload_scene(s, objT)
+    w = B.oracle_world(s)
+    for d in (0.0, 0.09):
+        eng.set_contact_distance(d)
+        w.set_contact_distance(d)
+        rec = eng.links_vs_all_poses(sets, robot)
+        recc = eng.cast_vs_all_poses(sets, robot, T1)
+        for k in range(nsets):
+            util.assert_same_contacts(util.records_to_contacts(rec[rec["problem"] == k]), w.links_vs_all(sets[k], robot), "disc set %d" % k)
+            util.assert_same_contacts(util.records_to_contacts(recc[recc["problem"] == k]),
+                                      w.cast_vs_all(sets[k], robot, sets[k][robot], T1[k]), "cast set %d" % k)
+    w.close()
+
+
+def _arm_world(active, boxes, seed=0):
+    s = M.Scene()
+    rb = synth.pr2_like(s, seed=seed, active=active)
+    ids, boxT = synth.add_boxes(s, boxes)
+    s.finalize(); rb.finalize()
+    static_T = np.tile(np.array(M.IDENT7), (s.n_objects, 1))
+    static_T[ids] = boxT
+    return s, rb, static_T
+
+
+TABLE = [((.85, .55, .01), synth.T7((1.1, 0, .635)))]  # data/table.xml
+
+
+@pytest.mark.parametrize("active,B_,T_", [("rightarm", 3, 10), ("fullbody", 2, 8)])
+def test_robot_linearization_vs_oracle(eng, active, B_, T_):
+    """FK + broadphase + narrowphase + Jacobian epilogue for B problems x T timesteps (configs 1-3 shape)."""
+    s, rb, static_T = _arm_world(active, TABLE + [((.2, .3, .4), synth.T7((0.6, -0.6, 0.4), (0, 0, 1), 0.5))])
+    rng = np.random.default_rng(11)
+    eng.upload_scene(s, static_T)
+    eng.upload_robot(rb)
+    w = B.oracle_world(s)
+    trajs = []
+    for b in range(B_):
+        q0 = rng.uniform(-0.6, 0.6, size=rb.K)
+        q1 = q0 + rng.uniform(-0.9, 0.9, size=rb.K)
+        if active == "rightarm":
+            q0 = rb.q_robot[1:8] + rng.uniform(-0.5, 0.5, size=7); q1 = q0 + rng.uniform(-0.9, 0.9, size=7)
+        trajs.append(synth.straight_line(q0, q1, T_))
+    dofs = np.stack(trajs)
+    # device FK against the oracle's FK
+    fk = eng.forward_kinematics(dofs.reshape(-1, rb.K))
+    for i, q in enumerate(dofs.reshape(-1, rb.K)):
+        assert np.abs(fk[i] - B.oracle_fk(rb, q)).max() < 1e-13
+    for d in (0.065, 0.09):
+        eng.set_contact_distance(d)
+        w.set_contact_distance(d)
+        for mask in (-1, M.GROUP_KINBODY):
+            rec, g = eng.links_vs_all_batch(dofs, B_, T_, filter_mask=mask)
+            for b in range(B_):
+                orec, og = w.linearize(rb, static_T, dofs[b], mask=mask)
+                sel = rec["problem"] == b
+                util.assert_same_linearization(rec[sel], g[sel], orec, og, "disc b=%d d=%g mask=%d" % (b, d, mask))
+        rec, g = eng.cast_vs_all_batch(dofs, B_, T_, gap=1)
+        ntot = 0
+        for b in range(B_):
+            orec, og = w.linearize(rb, static_T, dofs[b], cast=True)
+            sel = rec["problem"] == b
+            util.assert_same_linearization(rec[sel], g[sel], orec, og, "cast b=%d d=%g" % (b, d))
+            ntot += len(orec)
+        assert ntot > 0
+    # want_jacobians=0 (CalcDists path) returns the same contacts
+    rec0, g0 = eng.links_vs_all_batch(dofs, B_, T_, want_jacobians=False)
+    rec1, _ = eng.links_vs_all_batch(dofs, B_, T_)
+    assert g0 is None and np.array_equal(rec0["dist"], rec1["dist"]) and np.array_equal(rec0["idA"], rec1["idA"])
+    w.close()
+
+
+def test_allowed_matrix_and_group64_agree(eng):
+    s, rb, static_T = _arm_world("rightarm", TABLE)
+    eng.upload_scene(s, static_T)
+    eng.upload_robot(rb)
+    eng.set_contact_distance(0.1)
+    w = B.oracle_world(s)
+    w.set_contact_distance(0.1)
+    q = rb.q_robot[1:8][None]
+    # IgnoreZeroStateSelfCollisions-style exclusion: forbid every pair found in this pose, both directions
+    rec, _ = eng.links_vs_all_batch(q, 1, 1)
+    assert len(rec) > 0
+    m = np.ones((s.n_objects, s.n_objects), np.uint8)
+    m[rec["idA"], rec["idB"]] = 0
+    m[rec["idB"], rec["idA"]] = 0
+    eng.set_allowed_matrix(m)
+    w.set_allowed(m)
+    rec2, g2 = eng.links_vs_all_batch(q, 1, 1)
+    assert len(rec2) == 0
+    q2 = q + 0.4
+    rec3, g3 = eng.links_vs_all_batch(q2, 1, 1)
+    orec, og = w.linearize(rb, static_T, q2)
+    util.assert_same_linearization(rec3, g3, orec, og, "after exclusion")
+    w.close()
+
+
+def test_empty_and_error_paths(eng):
+    from trajopt_amd import engine
+    s, rb, static_T = _arm_world("rightarm", TABLE)
+    eng.upload_scene(s, static_T)
+    eng.upload_robot(rb)
+    eng.set_contact_distance(0.0)
+    far = static_T.copy()
+    rec = eng.links_vs_all_poses(far, [])          # empty query
+    assert len(rec) == 0
+    with pytest.raises(engine.EngineError):
+        eng.set_contact_distance(-1.0)
+    eng.set_capacity(16, 4)                         # too small on purpose: reported, not silently truncated
+    eng.set_contact_distance(0.2)
+    with pytest.raises(engine.EngineError):
+        eng.links_vs_all_batch(rb.q_robot[1:8][None], 1, 1)
+    eng.set_capacity(1 << 22, 1 << 18)
+    rec, _ = eng.links_vs_all_batch(rb.q_robot[1:8][None], 1, 1)
+    assert len(rec) > 0
+
+
+def test_fullsize_soup_properties(built):
+    """Config 4 (full body, 100 timesteps, 4096-hull soup, zero-state self-collision exclusions like the reference's
+    AddKinBody path): too big for the scalar oracle in the test budget, so check size-independent properties and
+    spot-check single timesteps against the oracle.  Goes through the host mirror of the reference interface."""
+    from trajopt_amd import collision_checker as CC
+    s, rb, static_T, d = synth.config_fullbody_soup()
+    cc = CC.CreateCollisionChecker(s, static_T)
+    cc.SetRobot(rb)                  # + IgnoreZeroStateSelfCollisions at d = 0.1
+    cc.SetContactDistance(d)
+    eng = cc.eng
+    assert (cc.allowed == 0).sum() > 0 and (cc.allowed == cc.allowed.T).all()
+    rng = np.random.default_rng(2)
+    traj = synth.fullbody_trajectory(rb, rng, 100)
+    rec, g = eng.links_vs_all_batch(traj, 1, 100)
+    c = eng.counters()
+    assert c["contacts"] == len(rec) > 0 and c["pair_evals"] >= len(rec)
+    # determinism / idempotence: a second call returns the identical slab
+    rec2, g2 = eng.links_vs_all_batch(traj, 1, 100)
+    assert np.array_equal(rec, rec2) and np.array_equal(g, g2)
+    # every record obeys the contact filter and the affine identity const0 + grad0.q = dist
+    assert (rec["dist"] <= np.float32(d)).all()
+    assert np.allclose(rec["const0"] + np.einsum("nk,nk->n", g[:, 0], traj[rec["t"]]), rec["dist"], atol=1e-9)
+    assert np.allclose(np.linalg.norm(rec["n"], axis=1), 1, atol=1e-5)
+    # timestep-sharding invariance (what multi-GPU sharding by timestep relies on)
+    sub, gs = eng.links_vs_all_batch(traj[40:50], 1, 10)
+    sel = (rec["t"] >= 40) & (rec["t"] < 50)
+    assert np.array_equal(sub["dist"], rec[sel]["dist"]) and np.array_equal(sub["idB"], rec[sel]["idB"]) and np.array_equal(gs, g[sel])
+    # resident API: discrete + cast appended into one slab == the two one-shot calls
+    recc, gc = eng.cast_vs_all_batch(traj, 1, 100, 1)
+    eng.stage_dofs(traj, 1, 100)
+    eng.enqueue_links_vs_all(-1, True, append=False)
+    eng.enqueue_cast_vs_all(1, True, append=True)
+    both, gboth = eng.fetch()
+    assert len(both) == len(rec) + len(recc)
+    disc = both["cctype"] == 0
+    assert np.array_equal(both[disc], rec) and np.array_equal(gboth[disc], g)
+    assert np.array_equal(both[~disc], recc) and np.array_equal(gboth[~disc], gc)
+    cnt = eng.counters()
+    assert cnt["pair_evals"] > 0 and cnt["cum_ms_gjk"] > 0
+    # spot check single timesteps against the oracle, discrete and cast
+    w = B.oracle_world(s, cap=1 << 17)
+    w.set_contact_distance(d)
+    w.set_allowed(cc.allowed)
+    for t in (0, 57, 98):
+        orec, og = w.linearize(rb, static_T, traj[t][None])
+        r = rec[rec["t"] == t].copy()
+        r["t"] = 0
+        util.assert_same_linearization(r, g[rec["t"] == t], orec, og, "soup disc t=%d" % t)
+        orec, og = w.linearize(rb, static_T, traj[t:t + 2], cast=True)
+        r = recc[recc["t"] == t].copy()
+        r["t"] = 0
+        util.assert_same_linearization(r, gc[recc["t"] == t], orec, og, "soup cast t=%d" % t)
+    w.close()
+    eng.close()

@@ -1,0 +1,239 @@
+"""CPU suite (-m "not gpu"): pins the oracle, the host logic and the C-ABI surface.
+
+  * reference known answers (collision-checker-unit.cpp:48-87,130-150): contact counts, the
+    -0.0577350222 diagonal-normal EPA answer, cast normals and times;
+  * golden fixtures recorded from the reference's own vendored Bullet (tests/golden/make_golden.py): bit-exact;
+  * where oracle/_ref/libref.so exists (build container), fresh random scenes against real Bullet: bit-exact;
+  * the device narrowphase source, compiled for the host (tests/emu): bit-exact against the oracle;
+  * FK / Jacobian: finite differences + closed-form planar arm (OpenRAVE parity is UNPINNED);
+  * libtrajopt_hipcc.so loads and exports every symbol of include/trajopt_hipcc.h; no compute without a GPU.
+"""
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import bindings as B
+from trajopt_amd import model as M, synth
+from tests import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "random_scene_*.npz")))
+
+
+def T(x, y=0, z=0):
+    return (1, 0, 0, 0, x, y, z)
+
+
+def two_boxes(group1):
+    s = M.Scene()
+    b = s.add_box(.5, .5, .5)
+    o0 = s.add_object([(b, M.IDENT7)], M.GROUP_KINBODY, name="box0")
+    o1 = s.add_object([(b, M.IDENT7)], group1, name="box1")
+    return s.finalize(), o0, o1
+
+
+WORLDS = [B.oracle_world, util.emu_world] + ([B.ref_world] if B.ref_available() else [])
+
+
+@pytest.mark.parametrize("mk", WORLDS)
+def test_reference_box_distance_known_answers(built, mk):
+    # collision-checker-unit.cpp:48-87
+    s, o0, o1 = two_boxes(M.GROUP_KINBODY)
+    w = mk(s)
+    expect = [(0, .9, 1), (0, 1.1, 0), (.04, 1.1, 0), (.1, 1.09, 1), (.2, 1.1, 1)]
+    for d, x, n in expect:
+        w.set_contact_distance(d)
+        c = w.links_vs_all([T(0), T(x)], [o0])
+        assert len(c) == n, (d, x)
+    # values observed from the reference's Bullet in the survey
+    w.set_contact_distance(0)
+    c = w.links_vs_all([T(0), T(.9)], [o0])[0]
+    assert np.float32(c["dist"]) == np.float32(-0.0577350222)
+    assert np.allclose(c["n"], [-0.57735, 0.57735, -0.57735], atol=1e-5)
+    w.set_contact_distance(.1)
+    c = w.links_vs_all([T(0), T(1.09)], [o0])[0]
+    assert np.float32(c["dist"]) == np.float32(0.0900000334) and np.array_equal(c["n"], [-1, 0, 0])
+    w.set_contact_distance(.2)
+    c = w.links_vs_all([T(0), T(1.1)], [o0])[0]
+    assert np.float32(c["dist"]) == np.float32(0.100000016) and np.array_equal(c["n"], [-1, 0, 0])
+    w.close()
+
+
+@pytest.mark.parametrize("mk", WORLDS)
+def test_reference_cast_known_answers(built, mk):
+    # collision-checker-unit.cpp:102-150 (CastVsAll part): boxbot swept past a box
+    s, box, bot = two_boxes(M.GROUP_ROBOT)
+    w = mk(s)
+    cases = [((-1.9, 0), (0, 1.9), (-1 / np.sqrt(2), 1 / np.sqrt(2), 0), .5, 1e-1),
+             ((0, .9), (0, 2), (0, 1, 0), 0, 1e-6), ((0, 2), (0, .9), (0, 1, 0), 1, 1e-6)]
+    for a, b, nrm, time, ttol in cases:
+        c = w.cast_vs_all([T(0), T(*a)], [bot], [T(*a)], [T(*b)])
+        assert len(c) == 1
+        robot_normal = (1 if c[0]["objA"] == bot else -1) * c[0]["n"]
+        assert np.allclose(robot_normal, nrm, atol=1e-4)
+        assert abs(c[0]["time"] - time) <= ttol
+        assert c[0]["objB"] == bot  # the collector orients the contact so the swept link is B
+    w.close()
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+@pytest.mark.parametrize("mk", [B.oracle_world, util.emu_world])
+def test_golden_fixtures_bit_exact(built, path, mk):
+    z = np.load(path, allow_pickle=False)
+    s = M.scene_from_arrays({k[6:]: z[k] for k in z.files if k.startswith("scene_")})
+    w = mk(s)
+    robot = z["robot"]
+    for i, d in enumerate(z["dists"]):
+        w.set_contact_distance(float(d))
+        util.assert_same_contacts(w.links_vs_all(z["objT"], robot), z["disc_%d" % i], "disc d=%g" % d)
+        util.assert_same_contacts(w.cast_vs_all(z["objT"], robot, z["objT"][robot], z["T1"]), z["cast_%d" % i], "cast d=%g" % d)
+    w.close()
+
+
+@pytest.mark.skipif(not B.ref_available(), reason="oracle/_ref/libref.so is only built where /root/reference exists")
+@pytest.mark.parametrize("seed", range(100, 112))
+def test_oracle_vs_reference_bullet_random(built, seed):
+    rng = np.random.default_rng(seed)
+    s, objT, robot = synth.random_scene(rng, spread=float(rng.choice([0.3, 0.6])))
+    wr, wo, we = B.ref_world(s), B.oracle_world(s), util.emu_world(s)
+    T1 = objT[robot].copy()
+    T1[:, 4:] += rng.normal(size=(len(robot), 3)) * 0.15
+    for d in (0.0, 0.09):
+        for w in (wr, wo, we):
+            w.set_contact_distance(d)
+        ref = wr.links_vs_all(objT, robot)
+        util.assert_same_contacts(wo.links_vs_all(objT, robot), ref, "oracle disc")
+        util.assert_same_contacts(we.links_vs_all(objT, robot), ref, "emu disc")
+        refc = wr.cast_vs_all(objT, robot, objT[robot], T1)
+        util.assert_same_contacts(wo.cast_vs_all(objT, robot, objT[robot], T1), refc, "oracle cast")
+        util.assert_same_contacts(we.cast_vs_all(objT, robot, objT[robot], T1), refc, "emu cast")
+    for w in (wr, wo, we):
+        w.close()
+
+
+def test_allowed_matrix_and_filter_mask(built):
+    rng = np.random.default_rng(7)
+    s, objT, robot = synth.random_scene(rng, spread=0.3)
+    w = B.oracle_world(s)
+    w.set_contact_distance(0.2)
+    full = w.links_vs_all(objT, robot)
+    assert len(full) > 0
+    only_env = w.links_vs_all(objT, robot, mask=M.GROUP_KINBODY)
+    groups = np.array(s.obj_group)
+    assert all(groups[c["objA"]] == M.GROUP_KINBODY or groups[c["objB"]] == M.GROUP_KINBODY for c in only_env)
+    assert len(only_env) < len(full)
+    m = np.ones((s.n_objects, s.n_objects), np.uint8)
+    a, b = int(full[0]["objA"]), int(full[0]["objB"])
+    m[a, b] = m[b, a] = 0
+    w.set_allowed(m)
+    cut = w.links_vs_all(objT, robot)
+    assert all({int(c["objA"]), int(c["objB"])} != {a, b} for c in cut) and len(cut) < len(full)
+    w.close()
+
+
+def test_empty_query_and_far_apart(built):
+    s, o0, o1 = two_boxes(M.GROUP_KINBODY)
+    w = B.oracle_world(s)
+    assert len(w.links_vs_all([T(0), T(50)], [o0])) == 0
+    assert len(w.links_vs_all([T(0), T(.5)], [])) == 0
+    w.close()
+
+
+# ---- FK / Jacobian ------------------------------------------------------------------------------------------
+def _quat_R(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+@pytest.mark.parametrize("active", ["rightarm", "fullbody"])
+def test_jacobian_matches_finite_differences(built, active):
+    s = M.Scene()
+    rb = synth.pr2_like(s, seed=0, active=active)
+    s.finalize(); rb.finalize()
+    rng = np.random.default_rng(3)
+    q = rng.uniform(-1, 1, size=rb.K)
+    _, links = rb.affected_links()
+    for link in links[::4]:
+        pl = rng.normal(size=3) * 0.1
+
+        def world_pt(qq):
+            Tl = B.oracle_fk(rb, qq)[link]
+            return _quat_R(Tl[:4]) @ pl + Tl[4:]
+
+        J = B.oracle_position_jacobian(rb, q, link, world_pt(q))
+        Jfd = np.stack([(world_pt(q + h) - world_pt(q - h)) / 2e-6 for h in np.eye(rb.K) * 1e-6], axis=1)
+        assert np.abs(J - Jfd).max() < 1e-7
+
+
+def test_fk_planar_three_links_closed_form(built):
+    # data/three_links.robot.xml: planar 3R arm, link lengths 0.16, 0.16
+    s = M.Scene()
+    rb = synth.three_links(s)
+    s.finalize(); rb.finalize()
+    q = np.array([0.3, -0.7, 1.1])
+    Tl = B.oracle_fk(rb, q)
+    a1, a2 = q[0], q[0] + q[1]
+    assert np.allclose(Tl[2][4:], [0.16 * np.cos(a1), 0.16 * np.sin(a1), 0], atol=1e-14)
+    assert np.allclose(Tl[3][4:], [0.16 * np.cos(a1) + 0.16 * np.cos(a2), 0.16 * np.sin(a1) + 0.16 * np.sin(a2), 0], atol=1e-14)
+    ang = q.sum()
+    assert np.allclose(Tl[3][:4], [np.cos(ang / 2), 0, 0, np.sin(ang / 2)], atol=1e-14)
+    # free rigid body known answer (src/sandbox/incremental_rb.hpp:45-54): J = [I | skew] -> for the planar base
+    s2 = M.Scene()
+    bot = synth.boxbot(s2)
+    bot.set_active([], M.DOF_X | M.DOF_Y | M.DOF_ROTAXIS)
+    s2.finalize(); bot.finalize()
+    J = B.oracle_position_jacobian(bot, np.array([.2, .3, .4]), 0, np.array([1.0, 2.0, 3.0]))
+    assert np.allclose(J, [[1, 0, -(2.0 - .3)], [0, 1, (1.0 - .2)], [0, 0, 0]])
+
+
+def test_linearization_is_first_order_accurate(built):
+    """const + grad.x reproduces the signed distance at x and predicts it nearby (collision_terms.cpp:37-62)."""
+    s = M.Scene()
+    rb = synth.pr2_like(s, seed=0, active="rightarm")
+    ids, boxT = synth.add_boxes(s, [((.85, .55, .01), synth.T7((1.1, 0, .635)))])
+    s.finalize(); rb.finalize()
+    static_T = np.tile(np.array(M.IDENT7), (s.n_objects, 1))
+    static_T[ids] = boxT
+    w = B.oracle_world(s)
+    w.set_contact_distance(0.2)
+    q = np.array([-0.4, 0.6, -0.5, -1.2, -1.0, -1.0, 1.0])
+    rec, g = w.linearize(rb, static_T, q[None], mask=M.GROUP_KINBODY)
+    assert len(rec) > 0
+    assert np.allclose(rec["const0"] + g[:, 0] @ q, rec["c"]["dist"], atol=1e-12)
+    dq = np.full(7, 1e-4)
+    rec2, _ = w.linearize(rb, static_T, (q + dq)[None], mask=M.GROUP_KINBODY)
+    k1 = {tuple(int(r["c"][k]) for k in util.KEYS): i for i, r in enumerate(rec)}
+    hits = 0
+    for r in rec2:
+        i = k1.get(tuple(int(r["c"][k]) for k in util.KEYS))
+        if i is not None and rec[i]["c"]["dist"] > 1e-3 and r["c"]["dist"] > 1e-3:
+            pred = rec[i]["const0"] + g[i, 0] @ (q + dq)
+            assert abs(pred - r["c"]["dist"]) < 5e-6
+            hits += 1
+    assert hits > 0
+    w.close()
+
+
+# ---- C-ABI surface ------------------------------------------------------------------------------------------
+def test_abi_library_exports_every_declared_symbol(built):
+    from trajopt_amd import engine
+    lib = engine.load_library()
+    hdr = open(os.path.join(ROOT, "include", "trajopt_hipcc.h")).read()
+    declared = set(re.findall(r"\b(tohc_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(engine.SYMBOLS), declared ^ set(engine.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_engine_fails_loudly_without_gpu(built):
+    import torch
+    from trajopt_amd import engine
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(engine.EngineError):
+        engine.Engine(0)

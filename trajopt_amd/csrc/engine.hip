@@ -55,7 +55,8 @@ struct DevRobot {
 };
 struct PairRec { int set, q, x, pad; };
 struct EpaRec { int pair; int isValid; float distance; float n[3]; float pB[3]; };
-struct Counters { unsigned int n_pairs, n_epa, n_records, overflow; };
+struct Counters { unsigned int n_pairs, n_epa, overflow, pad; };  // one per enqueue; the record counter is shared so
+                                                                   // that several enqueues can append to one slab
 
 struct CallParams {
   int n_cast_sets;   // number of (problem, t) units enumerated
@@ -229,6 +230,7 @@ struct NarrowArgs {
   const PairRec *pairs;
   EpaRec *epaq;
   Counters *cnt;
+  unsigned int *n_records;
   tohc_record *records;
   double *grads;          // [max_records][2][K]
 };
@@ -375,7 +377,7 @@ __device__ __forceinline__ void finishPair(const NarrowArgs &a, const PairCtx<G>
   }
   const int gl = Grp<G>::lane();
   unsigned int slot = 0;
-  if (gl == 0) slot = atomicAdd(&a.cnt->n_records, 1u);
+  if (gl == 0) slot = atomicAdd(a.n_records, 1u);
   slot = (unsigned int)__shfl((int)slot, 0, G);
   if (slot >= a.cp.max_records) {
     if (gl == 0) a.cnt->overflow = 1;
@@ -540,14 +542,26 @@ struct tohc_engine {
   DBuf<float> d_dynXf, d_dynAabb, d_dynXf1, d_dynAabb1;
   DBuf<PairRec> d_pairs;
   DBuf<EpaRec> d_epaq;
-  DBuf<Counters> d_cnt;
+  DBuf<Counters> d_cnt;            // [RING]
   DBuf<tohc_record> d_records;
   HBuf<tohc_record> h_records, h_sorted;
   HBuf<double> h_grads, h_gsorted;
-  HBuf<Counters> h_cnt;
+  HBuf<Counters> h_cnt;            // [RING]
   size_t max_pairs = (size_t)1 << 22, max_records = (size_t)1 << 18;
-  tohc_counters counters = {0, 0, 0, 0, 0.0};
+  tohc_counters counters;
+  // enqueue ring: every enqueue since the last sync has its own device counter slot and event set
+  struct Pending { int slot; int64_t aabb_tests; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> events;   // RING * 6
+  DBuf<unsigned int> d_nrec;        // shared record counter
+  HBuf<unsigned int> h_nrec;
+  int staged_B = 0, staged_T = 0;
+  bool staged = false;
+  bool last_robot_mode = true, last_want_jac = false;
+  size_t fetched_n = 0;
+  tohc_engine() { memset(&counters, 0, sizeof counters); }
 };
+static const int RING = 32;
 
 static int fail(tohc_engine *e, int code, const char *fmt, ...) {
   char buf[512];
@@ -598,6 +612,11 @@ int tohc_create(tohc_engine **out, int device) {
   const char *g = getenv("TOHC_GROUP");
   if (g && atoi(g) == 64) e->group = 64;
   e->breaking = (float)(2.001 * (double)e->d);
+  e->events.resize((size_t)RING * 6);
+  for (auto &ev : e->events)
+    if (hipEventCreate(&ev) != hipSuccess) { delete e; return TOHC_E_HIP; }
+  if (e->d_cnt.reserve(RING) != hipSuccess || e->h_cnt.reserve(RING) != hipSuccess || e->d_nrec.reserve(1) != hipSuccess ||
+      e->h_nrec.reserve(1) != hipSuccess || hipMemset(e->d_nrec.p, 0, sizeof(unsigned int)) != hipSuccess) { delete e; return TOHC_E_HIP; }
   *out = e;
   return TOHC_OK;
 }
@@ -619,6 +638,8 @@ void tohc_destroy(tohc_engine *e) {
   e->d_allowed.release(); e->d_pairs.release(); e->d_epaq.release(); e->d_cnt.release(); e->d_records.release();
   e->h_records.release(); e->h_sorted.release(); e->h_grads.release(); e->h_gsorted.release(); e->h_cnt.release();
   (void)hipEventDestroy(e->ev0); (void)hipEventDestroy(e->ev1);
+  for (auto ev : e->events) (void)hipEventDestroy(ev);
+  e->d_nrec.release(); e->h_nrec.release();
   (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -857,83 +878,199 @@ static DevRobot devRobot(tohc_engine *e) {
   return r;
 }
 
-// shared tail of every query: broadphase -> GJK -> EPA -> copy back -> canonical order
-static int runQuery(tohc_engine *e, const DynMap &dm, const int *d_qchildren, const std::vector<int> &h_qchildren, CallParams cp, int n_sets,
-                    bool robotMode, const tohc_record **records, const double **grads, int *n_records) {
+// -----------------------------------------------------------------------------------------------------------------
+// stage -> enqueue -> sync -> fetch.  The one-shot batch calls are exactly these four in a row.
+// -----------------------------------------------------------------------------------------------------------------
+static int syncEngine(tohc_engine *e) {
+  hipStream_t s = e->stream;
+  if (e->pending.empty()) { HIPCHK(hipStreamSynchronize(s)); return TOHC_OK; }
+  HIPCHK(hipMemcpyAsync(e->h_cnt.p, e->d_cnt.p, sizeof(Counters) * RING, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(e->h_nrec.p, e->d_nrec.p, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  bool overflow = false;
+  unsigned int worst_pairs = 0;
+  tohc_counters &c = e->counters;
+  c.aabb_tests = c.pair_evals = c.epa_evals = 0;
+  c.ms_last_call = 0;
+  for (const auto &pd : e->pending) {
+    const Counters &k = e->h_cnt.p[pd.slot];
+    overflow |= k.overflow != 0 || k.n_pairs > e->max_pairs;
+    worst_pairs = std::max(worst_pairs, k.n_pairs);
+    c.aabb_tests += pd.aabb_tests; c.pair_evals += k.n_pairs; c.epa_evals += k.n_epa;
+    c.cum_aabb_tests += pd.aabb_tests; c.cum_pair_evals += k.n_pairs; c.cum_epa_evals += k.n_epa;
+    float ms[5] = {0, 0, 0, 0, 0};
+    hipEvent_t *ev = &e->events[(size_t)pd.slot * 6];
+    for (int i = 0; i < 5; ++i) HIPCHK(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+    c.cum_ms_fk += ms[0]; c.cum_ms_children += ms[1]; c.cum_ms_broadphase += ms[2]; c.cum_ms_gjk += ms[3]; c.cum_ms_epa += ms[4];
+    c.ms_last_call += ms[0] + ms[1] + ms[2] + ms[3] + ms[4];
+    c.cum_launches += 1;
+  }
+  e->pending.clear();
+  const unsigned int nrec = *e->h_nrec.p;
+  c.contacts = nrec;
+  if (overflow || nrec > e->max_records)
+    return fail(e, TOHC_E_CAPACITY, "capacity exceeded: %u pairs in one enqueue (max %zu), %u records (max %zu); raise with tohc_set_capacity",
+                worst_pairs, e->max_pairs, nrec, e->max_records);
+  return TOHC_OK;
+}
+
+static int64_t countAabbTests(const tohc_engine *e, const std::vector<int> &qchildren, const CallParams &cp) {
+  // tuples the broadphase examines = units x (query child, other child) combinations that pass the object filters
+  int64_t per = 0;
+  for (int q : qchildren) {
+    int Q = e->h_child_obj[q];
+    for (int X = 0; X < e->n_objects; ++X) {
+      if (X == Q) continue;
+      int g = e->h_obj_group[X];
+      if (cp.cast ? !(g & TOHC_GROUP_KINBODY) : !(g & (short)cp.filter_mask)) continue;
+      if (!e->h_allowed[(size_t)Q * e->n_objects + X]) continue;
+      per += e->h_obj_cnt[X];
+    }
+  }
+  return per * cp.n_cast_sets;
+}
+
+// broadphase -> GJK -> EPA for one enqueue; `ev` = this enqueue's events [2..5] are recorded here
+static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren, const std::vector<int> &h_qchildren, CallParams cp,
+                        bool robotMode, int slot, bool append) {
   const int nQ = (int)h_qchildren.size();
   const int K = robotMode ? e->K : 1;
-  *n_records = 0;
-  if (records) *records = nullptr;
-  if (grads) *grads = nullptr;
   hipStream_t s = e->stream;
-  HIPCHK(e->d_cnt.reserve(1)); HIPCHK(e->h_cnt.reserve(1));
-  HIPCHK(hipMemsetAsync(e->d_cnt.p, 0, sizeof(Counters), s));
-  e->counters.aabb_tests = 0; e->counters.pair_evals = 0; e->counters.epa_evals = 0; e->counters.contacts = 0;
-  if (nQ == 0 || cp.n_cast_sets <= 0) { HIPCHK(hipStreamSynchronize(s)); return TOHC_OK; }
+  hipEvent_t *ev = &e->events[(size_t)slot * 6];
+  HIPCHK(hipMemsetAsync(e->d_cnt.p + slot, 0, sizeof(Counters), s));
+  if (!append) HIPCHK(hipMemsetAsync(e->d_nrec.p, 0, sizeof(unsigned int), s));
   cp.max_pairs = (unsigned int)e->max_pairs; cp.max_records = (unsigned int)e->max_records;
   HIPCHK(e->d_pairs.reserve(e->max_pairs)); HIPCHK(e->d_epaq.reserve(e->max_pairs));
   HIPCHK(e->d_records.reserve(e->max_records));
   HIPCHK(e->d_grads.reserve(e->max_records * 2 * (size_t)K));
-  DevScene sc = devScene(e);
-  const int BT = 256;
-  const int xTiles = (e->n_children + BT - 1) / BT;
-  const size_t blocks = (size_t)cp.n_cast_sets * nQ * xTiles;
-  if (blocks > 0x7fffffffull) return fail(e, TOHC_E_CAPACITY, "broadphase grid too large (%zu blocks)", blocks);
-  hipLaunchKernelGGL(k_broadphase, dim3((unsigned)blocks), dim3(BT), 0, s, sc, dm, cp, d_qchildren, nQ, e->d_dynAabb.p,
-                     cp.gap == 0 && cp.cast ? e->d_dynAabb1.p : e->d_dynAabb.p, e->d_pairs.p, e->d_cnt.p);
-  NarrowArgs a;
-  a.sc = sc; a.dm = dm; a.rb = devRobot(e); a.cp = cp;
-  a.dynXf0 = e->d_dynXf.p; a.dynXf1 = (cp.gap == 0 && cp.cast) ? e->d_dynXf1.p : e->d_dynXf.p;
-  a.linkQT = robotMode ? e->d_linkQT.p : nullptr;
-  a.dofs = robotMode ? e->d_dofs.p : nullptr;
-  a.pairs = e->d_pairs.p; a.epaq = e->d_epaq.p; a.cnt = e->d_cnt.p; a.records = e->d_records.p; a.grads = e->d_grads.p;
-  const int gridN = 256 * 8;
-  if (e->group == 64) {
-    hipLaunchKernelGGL((k_gjk<64>), dim3(gridN), dim3(256), 0, s, a);
-    hipLaunchKernelGGL((k_epa<64, 64>), dim3(gridN), dim3(64), 0, s, a);
+  HIPCHK(hipEventRecord(ev[2], s));
+  if (nQ > 0 && cp.n_cast_sets > 0) {
+    DevScene sc = devScene(e);
+    const int BT = 256;
+    const int xTiles = (e->n_children + BT - 1) / BT;
+    const size_t blocks = (size_t)cp.n_cast_sets * nQ * xTiles;
+    if (blocks > 0x7fffffffull) return fail(e, TOHC_E_CAPACITY, "broadphase grid too large (%zu blocks)", blocks);
+    const bool sep1 = cp.gap == 0 && cp.cast;  // poses mode keeps the end-of-sweep poses in their own tables
+    hipLaunchKernelGGL(k_broadphase, dim3((unsigned)blocks), dim3(BT), 0, s, sc, dm, cp, d_qchildren, nQ, e->d_dynAabb.p,
+                       sep1 ? e->d_dynAabb1.p : e->d_dynAabb.p, e->d_pairs.p, e->d_cnt.p + slot);
+    HIPCHK(hipEventRecord(ev[3], s));
+    NarrowArgs a;
+    a.sc = sc; a.dm = dm; a.rb = devRobot(e); a.cp = cp;
+    a.dynXf0 = e->d_dynXf.p; a.dynXf1 = sep1 ? e->d_dynXf1.p : e->d_dynXf.p;
+    a.linkQT = robotMode ? e->d_linkQT.p : nullptr;
+    a.dofs = robotMode ? e->d_dofs.p : nullptr;
+    a.pairs = e->d_pairs.p; a.epaq = e->d_epaq.p; a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p;
+    a.records = e->d_records.p; a.grads = e->d_grads.p;
+    const int gridN = 256 * 8;
+    if (e->group == 64) hipLaunchKernelGGL((k_gjk<64>), dim3(gridN), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_gjk<16>), dim3(gridN), dim3(256), 0, s, a);
+    HIPCHK(hipEventRecord(ev[4], s));
+    if (e->group == 64) hipLaunchKernelGGL((k_epa<64, 64>), dim3(gridN), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((k_epa<16, 64>), dim3(gridN), dim3(64), 0, s, a);
+    HIPCHK(hipEventRecord(ev[5], s));
+    HIPCHK(hipGetLastError());
   } else {
-    hipLaunchKernelGGL((k_gjk<16>), dim3(gridN), dim3(256), 0, s, a);
-    hipLaunchKernelGGL((k_epa<16, 64>), dim3(gridN), dim3(64), 0, s, a);
+    HIPCHK(hipEventRecord(ev[3], s)); HIPCHK(hipEventRecord(ev[4], s)); HIPCHK(hipEventRecord(ev[5], s));
   }
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(e->h_cnt.p, e->d_cnt.p, sizeof(Counters), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipEventRecord(e->ev1, s));
-  HIPCHK(hipStreamSynchronize(s));
-  float ms = 0;
-  HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
-  e->counters.ms_last_call = ms;
-  const Counters c = *e->h_cnt.p;
-  // tuples the broadphase examined = (units) x (query child, other child) combinations that pass the object filters
-  {
-    int64_t per = 0;
-    for (int q : h_qchildren) {
-      int Q = e->h_child_obj[q];
-      for (int X = 0; X < e->n_objects; ++X) {
-        if (X == Q) continue;
-        int g = e->h_obj_group[X];
-        if (cp.cast ? !(g & TOHC_GROUP_KINBODY) : !(g & (short)cp.filter_mask)) continue;
-        if (!e->h_allowed[(size_t)Q * e->n_objects + X]) continue;
-        per += e->h_obj_cnt[X];
-      }
-    }
-    e->counters.aabb_tests = per * cp.n_cast_sets;
+  tohc_engine::Pending pd;
+  pd.slot = slot;
+  pd.aabb_tests = countAabbTests(e, h_qchildren, cp);
+  e->pending.push_back(pd);
+  e->last_robot_mode = robotMode;
+  e->last_want_jac = robotMode && cp.want_jac;
+  return TOHC_OK;
+}
+
+static int nextSlot(tohc_engine *e, int *slot) {
+  if ((int)e->pending.size() >= RING) {
+    int rc = syncEngine(e);
+    if (rc != TOHC_OK) return rc;
   }
-  e->counters.pair_evals = c.n_pairs; e->counters.epa_evals = c.n_epa; e->counters.contacts = c.n_records;
-  if (c.overflow || c.n_pairs > e->max_pairs || c.n_records > e->max_records)
-    return fail(e, TOHC_E_CAPACITY, "capacity exceeded: %u pairs (max %zu), %u records (max %zu); raise with tohc_set_capacity", c.n_pairs,
-                e->max_pairs, c.n_records, e->max_records);
-  const size_t n = c.n_records;
-  (void)n_sets;
+  *slot = (int)e->pending.size();
+  return TOHC_OK;
+}
+
+int tohc_stage_dofs(tohc_engine *e, const double *dofs, int B, int T) {
+  if (!e) return TOHC_E_INVALID;
+  if (!e->have_scene || !e->have_robot) return fail(e, TOHC_E_STATE, "upload the scene and the robot first");
+  if (!dofs || B < 1 || T < 1) return fail(e, TOHC_E_INVALID, "dofs is null or B/T < 1");
+  HIPCHK(hipSetDevice(e->device));
+  const size_t n_sets = (size_t)B * T;
+  HIPCHK(upload(e->d_dofs, dofs, n_sets * e->K, e->stream));
+  HIPCHK(e->d_linkQT.reserve(n_sets * e->n_links * 7));
+  HIPCHK(e->d_objQT.reserve(n_sets * std::max(e->n_dyn_objR, 1) * 7));
+  HIPCHK(e->d_dynXf.reserve(n_sets * std::max(e->n_dyn_childrenR, 1) * 12));
+  HIPCHK(e->d_dynAabb.reserve(n_sets * std::max(e->n_dyn_childrenR, 1) * 6));
+  HIPCHK(hipStreamSynchronize(e->stream));  // the caller's buffer may go away
+  e->staged_B = B; e->staged_T = T; e->staged = true;
+  return TOHC_OK;
+}
+
+static int enqueueRobot(tohc_engine *e, int gap, int cast, int filter_mask, int want_jac, int append) {
+  if (!e) return TOHC_E_INVALID;
+  if (!e->staged) return fail(e, TOHC_E_STATE, "stage the DOF vectors first (tohc_stage_dofs)");
+  if (cast && gap < 1) return fail(e, TOHC_E_INVALID, "cast: gap must be >= 1");
+  HIPCHK(hipSetDevice(e->device));
+  int slot;
+  int rc = nextSlot(e, &slot);
+  if (rc != TOHC_OK) return rc;
+  const int B = e->staged_B, T = e->staged_T;
+  const size_t n_sets = (size_t)B * T;
+  hipStream_t s = e->stream;
+  hipEvent_t *ev = &e->events[(size_t)slot * 6];
+  HIPCHK(hipEventRecord(ev[0], s));
+  hipLaunchKernelGGL(k_fk, dim3((unsigned)((n_sets + 63) / 64)), dim3(64), 0, s, devRobot(e), e->d_dofs.p, (int)n_sets, e->d_linkQT.p, e->d_objQT.p,
+                     e->n_dyn_objR);
+  HIPCHK(hipEventRecord(ev[1], s));
+  DynMap dm;
+  dm.obj_dyn = e->d_obj_dynR.p; dm.child_dyn = e->d_child_dynR.p; dm.n_dyn_obj = e->n_dyn_objR; dm.n_dyn_children = e->n_dyn_childrenR;
+  const size_t tot = n_sets * e->n_dyn_childrenR;
+  if (tot > 0)
+    hipLaunchKernelGGL(k_dyn_children, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, devScene(e), dm, e->d_dyn_childrenR.p, e->d_objQT.p,
+                       (int)n_sets, e->d, e->d_dynXf.p, e->d_dynAabb.p);
+  CallParams cp;
+  memset(&cp, 0, sizeof cp);
+  cp.T = T; cp.gap = cast ? gap : 0; cp.cast = cast; cp.filter_mask = filter_mask; cp.want_jac = want_jac; cp.d = e->d; cp.breaking = e->breaking;
+  cp.n_cast_sets = cast ? B * std::max(T - gap, 0) : B * T;
+  return launchNarrow(e, dm, e->d_qchildrenR.p, e->h_qchildrenR, cp, true, slot, append != 0);
+}
+
+int tohc_enqueue_links_vs_all(tohc_engine *e, int filter_mask, int want_jacobians, int append) {
+  return enqueueRobot(e, 0, 0, filter_mask, want_jacobians, append);
+}
+int tohc_enqueue_cast_vs_all(tohc_engine *e, int gap, int want_jacobians, int append) {
+  return enqueueRobot(e, gap, 1, -1, want_jacobians, append);
+}
+
+int tohc_sync(tohc_engine *e) {
+  if (!e) return TOHC_E_INVALID;
+  HIPCHK(hipSetDevice(e->device));
+  return syncEngine(e);
+}
+
+int tohc_fetch(tohc_engine *e, const tohc_record **records, const double **grads, int *n_records) {
+  if (!e) return TOHC_E_INVALID;
+  if (!n_records) return fail(e, TOHC_E_INVALID, "n_records is null");
+  *n_records = 0;
+  if (records) *records = nullptr;
+  if (grads) *grads = nullptr;
+  HIPCHK(hipSetDevice(e->device));
+  int rc = syncEngine(e);
+  if (rc != TOHC_OK) return rc;
+  const size_t n = *e->h_nrec.p;
   if (n == 0) return TOHC_OK;
+  hipStream_t s = e->stream;
+  const int K = e->last_robot_mode ? e->K : 1;
   HIPCHK(e->h_records.reserve(n)); HIPCHK(e->h_sorted.reserve(n));
   HIPCHK(hipMemcpyAsync(e->h_records.p, e->d_records.p, n * sizeof(tohc_record), hipMemcpyDeviceToHost, s));
-  const bool haveG = robotMode && cp.want_jac;
+  const bool haveG = e->last_want_jac;
   if (haveG) {
     HIPCHK(e->h_grads.reserve(n * 2 * K)); HIPCHK(e->h_gsorted.reserve(n * 2 * K));
     HIPCHK(hipMemcpyAsync(e->h_grads.p, e->d_grads.p, n * 2 * K * sizeof(double), hipMemcpyDeviceToHost, s));
   }
   HIPCHK(hipStreamSynchronize(s));
-  // canonical order: Bullet's own order follows DBVT traversal and is history dependent
+  // canonical order: Bullet's own order follows DBVT traversal and is history dependent.
+  // discrete records (cctype none) sort before cast records of the same (problem, t) when both were appended.
   std::vector<uint32_t> idx(n);
   std::iota(idx.begin(), idx.end(), 0u);
   const tohc_record *r = e->h_records.p;
@@ -941,6 +1078,8 @@ static int runQuery(tohc_engine *e, const DynMap &dm, const int *d_qchildren, co
     const tohc_record &a = r[i], &b = r[j];
     if (a.problem != b.problem) return a.problem < b.problem;
     if (a.t != b.t) return a.t < b.t;
+    const int ca = a.cctype != 0, cb = b.cctype != 0;
+    if (ca != cb) return ca < cb;
     if (a.idA != b.idA) return a.idA < b.idA;
     if (a.childA != b.childA) return a.childA < b.childA;
     if (a.idB != b.idB) return a.idB < b.idB;
@@ -956,45 +1095,19 @@ static int runQuery(tohc_engine *e, const DynMap &dm, const int *d_qchildren, co
   return TOHC_OK;
 }
 
-static int robotBatch(tohc_engine *e, const double *dofs, int B, int T, int gap, int cast, int filter_mask, int want_jac,
-                      const tohc_record **records, const double **grads, int *n_records) {
-  if (!e) return TOHC_E_INVALID;
-  if (!n_records) return fail(e, TOHC_E_INVALID, "n_records is null");
-  *n_records = 0;
-  if (!e->have_scene || !e->have_robot) return fail(e, TOHC_E_STATE, "upload the scene and the robot first");
-  if (!dofs || B < 1 || T < 1) return fail(e, TOHC_E_INVALID, "dofs is null or B/T < 1");
-  if (cast && (gap < 1)) return fail(e, TOHC_E_INVALID, "cast: gap must be >= 1");
-  HIPCHK(hipSetDevice(e->device));
-  const size_t n_sets = (size_t)B * T;
-  hipStream_t s = e->stream;
-  HIPCHK(hipEventRecord(e->ev0, s));
-  HIPCHK(upload(e->d_dofs, dofs, n_sets * e->K, s));
-  HIPCHK(e->d_linkQT.reserve(n_sets * e->n_links * 7));
-  HIPCHK(e->d_objQT.reserve(n_sets * std::max(e->n_dyn_objR, 1) * 7));
-  HIPCHK(e->d_dynXf.reserve(n_sets * std::max(e->n_dyn_childrenR, 1) * 12));
-  HIPCHK(e->d_dynAabb.reserve(n_sets * std::max(e->n_dyn_childrenR, 1) * 6));
-  DevRobot rb = devRobot(e);
-  hipLaunchKernelGGL(k_fk, dim3((unsigned)((n_sets + 63) / 64)), dim3(64), 0, s, rb, e->d_dofs.p, (int)n_sets, e->d_linkQT.p, e->d_objQT.p, e->n_dyn_objR);
-  DynMap dm;
-  dm.obj_dyn = e->d_obj_dynR.p; dm.child_dyn = e->d_child_dynR.p; dm.n_dyn_obj = e->n_dyn_objR; dm.n_dyn_children = e->n_dyn_childrenR;
-  const size_t tot = n_sets * e->n_dyn_childrenR;
-  if (tot > 0)
-    hipLaunchKernelGGL(k_dyn_children, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, devScene(e), dm, e->d_dyn_childrenR.p, e->d_objQT.p,
-                       (int)n_sets, e->d, e->d_dynXf.p, e->d_dynAabb.p);
-  CallParams cp;
-  memset(&cp, 0, sizeof cp);
-  cp.T = T; cp.gap = cast ? gap : 0; cp.cast = cast; cp.filter_mask = filter_mask; cp.want_jac = want_jac; cp.d = e->d; cp.breaking = e->breaking;
-  cp.n_cast_sets = cast ? B * std::max(T - gap, 0) : B * T;
-  return runQuery(e, dm, e->d_qchildrenR.p, e->h_qchildrenR, cp, (int)n_sets, true, records, grads, n_records);
-}
-
 int tohc_links_vs_all_batch(tohc_engine *e, const double *dofs, int B, int T, int filter_mask, int want_jacobians, const tohc_record **records,
                             const double **grads, int *n_records) {
-  return robotBatch(e, dofs, B, T, 0, 0, filter_mask, want_jacobians, records, grads, n_records);
+  int rc = tohc_stage_dofs(e, dofs, B, T);
+  if (rc == TOHC_OK) rc = tohc_enqueue_links_vs_all(e, filter_mask, want_jacobians, 0);
+  if (rc == TOHC_OK) rc = tohc_fetch(e, records, grads, n_records);
+  return rc;
 }
 int tohc_cast_vs_all_batch(tohc_engine *e, const double *dofs, int B, int T, int gap, int want_jacobians, const tohc_record **records,
                            const double **grads, int *n_records) {
-  return robotBatch(e, dofs, B, T, gap, 1, -1, want_jacobians, records, grads, n_records);
+  int rc = tohc_stage_dofs(e, dofs, B, T);
+  if (rc == TOHC_OK) rc = tohc_enqueue_cast_vs_all(e, gap, want_jacobians, 0);
+  if (rc == TOHC_OK) rc = tohc_fetch(e, records, grads, n_records);
+  return rc;
 }
 
 static int posesQuery(tohc_engine *e, const double *obj_T, const double *cast_T1, int n_sets, const int32_t *query, int n_query, int filter_mask,
@@ -1014,8 +1127,14 @@ static int posesQuery(tohc_engine *e, const double *obj_T, const double *cast_T1
     seen[o] = 1;
     for (int k = 0; k < e->h_obj_cnt[o]; ++k) qch.push_back(e->h_obj_off[o] + k);
   }
+  int slot;
+  int rc = nextSlot(e, &slot);
+  if (rc != TOHC_OK) return rc;
+  e->staged = false;  // the pose tables below overwrite the staged robot tables
   hipStream_t s = e->stream;
-  HIPCHK(hipEventRecord(e->ev0, s));
+  hipEvent_t *ev = &e->events[(size_t)slot * 6];
+  HIPCHK(hipEventRecord(ev[0], s));
+  HIPCHK(hipEventRecord(ev[1], s));
   const size_t nobj = e->n_objects, nch = e->n_children;
   HIPCHK(upload(e->d_objQT, obj_T, (size_t)n_sets * nobj * 7, s));
   HIPCHK(upload(e->d_qchildrenP, qch, s));
@@ -1035,14 +1154,16 @@ static int posesQuery(tohc_engine *e, const double *obj_T, const double *cast_T1
     HIPCHK(e->d_dynXf1.reserve((size_t)n_sets * nch * 12)); HIPCHK(e->d_dynAabb1.reserve((size_t)n_sets * nch * 6));
     hipLaunchKernelGGL(k_dyn_children, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, devScene(e), dm, e->d_dyn_childrenP.p, e->d_objQT1.p,
                        n_sets, e->d, e->d_dynXf1.p, e->d_dynAabb1.p);
-    HIPCHK(hipStreamSynchronize(s));  // T1 is a local buffer
   }
+  HIPCHK(hipStreamSynchronize(s));  // caller-owned / local host buffers may go away
   CallParams cp;
   memset(&cp, 0, sizeof cp);
   cp.T = 1; cp.gap = 0; cp.cast = cast; cp.filter_mask = filter_mask; cp.want_jac = 0; cp.d = e->d; cp.breaking = e->breaking;
   cp.n_cast_sets = n_sets;
+  rc = launchNarrow(e, dm, e->d_qchildrenP.p, qch, cp, false, slot, false);
+  if (rc != TOHC_OK) return rc;
   const double *g = nullptr;
-  return runQuery(e, dm, e->d_qchildrenP.p, qch, cp, n_sets, false, records, &g, n_records);
+  return tohc_fetch(e, records, &g, n_records);
 }
 
 int tohc_links_vs_all_poses(tohc_engine *e, const double *obj_T, int n_sets, const int32_t *query, int n_query, int filter_mask,
@@ -1059,6 +1180,9 @@ int tohc_forward_kinematics(tohc_engine *e, const double *dofs, int n_cfg, doubl
   if (!e->have_robot) return fail(e, TOHC_E_STATE, "upload the robot first");
   if (!dofs || !link_T || n_cfg < 1) return fail(e, TOHC_E_INVALID, "null input");
   HIPCHK(hipSetDevice(e->device));
+  int rc = syncEngine(e);
+  if (rc != TOHC_OK) return rc;
+  e->staged = false;
   hipStream_t s = e->stream;
   HIPCHK(upload(e->d_dofs, dofs, (size_t)n_cfg * e->K, s));
   HIPCHK(e->d_linkQT.reserve((size_t)n_cfg * e->n_links * 7));

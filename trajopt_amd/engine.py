@@ -20,7 +20,10 @@ assert RECORD_DTYPE.itemsize == 152
 
 class Counters(C.Structure):
     _fields_ = [("aabb_tests", C.c_int64), ("pair_evals", C.c_int64), ("epa_evals", C.c_int64),
-                ("contacts", C.c_int64), ("ms_last_call", C.c_double)]
+                ("contacts", C.c_int64), ("ms_last_call", C.c_double),
+                ("cum_aabb_tests", C.c_int64), ("cum_pair_evals", C.c_int64), ("cum_epa_evals", C.c_int64),
+                ("cum_launches", C.c_int64), ("cum_ms_fk", C.c_double), ("cum_ms_children", C.c_double),
+                ("cum_ms_broadphase", C.c_double), ("cum_ms_gjk", C.c_double), ("cum_ms_epa", C.c_double)]
 
 
 class EngineError(RuntimeError):
@@ -50,6 +53,11 @@ SYMBOLS = {
                                           C.POINTER(_f64p), C.POINTER(C.c_int)]),
     "tohc_cast_vs_all_batch": (C.c_int, [C.c_void_p, _f64p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
                                          C.POINTER(_f64p), C.POINTER(C.c_int)]),
+    "tohc_stage_dofs": (C.c_int, [C.c_void_p, _f64p, C.c_int, C.c_int]),
+    "tohc_enqueue_links_vs_all": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "tohc_enqueue_cast_vs_all": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "tohc_sync": (C.c_int, [C.c_void_p]),
+    "tohc_fetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(_f64p), C.POINTER(C.c_int)]),
     "tohc_links_vs_all_poses": (C.c_int, [C.c_void_p, _f64p, C.c_int, _i32p, C.c_int, C.c_int, C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_int)]),
     "tohc_cast_vs_all_poses": (C.c_int, [C.c_void_p, _f64p, _f64p, C.c_int, _i32p, C.c_int, C.POINTER(C.c_void_p),
@@ -173,6 +181,26 @@ class Engine:
                                                   C.byref(rec), C.byref(g), C.byref(n)))
         return self._collect(rec, g, n, self.K, copy)
 
+    # resident pieces: stage once, enqueue many times, fetch when the host needs the slab
+    def stage_dofs(self, dofs, B, T):
+        dofs = np.ascontiguousarray(dofs, np.float64)
+        assert dofs.size == B * T * self.K
+        self._chk(self.lib.tohc_stage_dofs(self.h, _p(dofs, C.c_double), B, T))
+
+    def enqueue_links_vs_all(self, filter_mask=-1, want_jacobians=True, append=False):
+        self._chk(self.lib.tohc_enqueue_links_vs_all(self.h, int(filter_mask), int(want_jacobians), int(append)))
+
+    def enqueue_cast_vs_all(self, gap=1, want_jacobians=True, append=False):
+        self._chk(self.lib.tohc_enqueue_cast_vs_all(self.h, int(gap), int(want_jacobians), int(append)))
+
+    def sync(self):
+        self._chk(self.lib.tohc_sync(self.h))
+
+    def fetch(self, copy=True):
+        rec, g, n = C.c_void_p(), _f64p(), C.c_int()
+        self._chk(self.lib.tohc_fetch(self.h, C.byref(rec), C.byref(g), C.byref(n)))
+        return self._collect(rec, g, n, self.K, copy)
+
     def links_vs_all_poses(self, obj_T, query, filter_mask=-1):
         obj_T = np.ascontiguousarray(obj_T, np.float64).reshape(-1, self.n_objects, 7)
         q = np.ascontiguousarray(query, np.int32)
@@ -199,5 +227,4 @@ class Engine:
     def counters(self):
         c = Counters()
         self._chk(self.lib.tohc_get_counters(self.h, C.byref(c)))
-        return dict(aabb_tests=c.aabb_tests, pair_evals=c.pair_evals, epa_evals=c.epa_evals, contacts=c.contacts,
-                    ms_last_call=c.ms_last_call)
+        return {name: getattr(c, name) for name, _ in Counters._fields_}

@@ -89,6 +89,19 @@ class Scene:
         return self
 
 
+def scene_from_arrays(arrays):
+    """Rebuild a finalized Scene from its flat arrays (e.g. a tests/golden fixture)."""
+    s = Scene()
+    s.arrays = {k: np.ascontiguousarray(v) for k, v in arrays.items()}
+    a = s.arrays
+    s.obj_off, s.obj_cnt = a["obj_off"].tolist(), a["obj_cnt"].tolist()
+    s.obj_compound, s.obj_group = a["obj_compound"].tolist(), a["obj_group"].tolist()
+    s.child_shape = a["child_shape"].tolist()
+    s.kind = a["kind"].tolist()
+    s.obj_name = ["obj%d" % i for i in range(len(s.obj_off))]
+    return s
+
+
 class RobotModel:
     """Flattened kinematic tree + the active DOFs of a RobotAndDOF (configuration_space.hpp).
 

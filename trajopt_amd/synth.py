@@ -221,3 +221,46 @@ def convex_soup(scene, n_hulls=4096, seed=2, extent=3.0, sigma=0.03, center=(1.5
 
 def straight_line(q0, q1, T):
     return np.linspace(np.asarray(q0, float), np.asarray(q1, float), T)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# named workloads (BASELINE.json configs)
+# ------------------------------------------------------------------------------------------------------------
+TABLE_BOX = ((.85, .55, .01), T7((1.1, 0, .635)))   # data/table.xml
+
+
+def static_poses(scene, ids=(), poses=None):
+    st = np.tile(np.array(M.IDENT7), (scene.n_objects, 1))
+    if len(ids):
+        st[list(ids)] = poses
+    return st
+
+
+def config_arm_table(seed=0):
+    """Configs 1/2: PR2-like right arm (K=7) over the table of data/table.xml; d = 0.025 + 0.04."""
+    s = M.Scene()
+    rb = pr2_like(s, seed=seed, active="rightarm")
+    ids, T = add_boxes(s, [TABLE_BOX], name="table")
+    s.finalize(); rb.finalize()
+    return s, rb, static_poses(s, ids, T), 0.065
+
+
+def config_fullbody_soup(n_hulls=4096, seed=2):
+    """Config 4: full-body PR2-like robot (K=18: torso + 2 arms + base x,y,theta) in front of a 4096-hull convex soup
+    (one object with 4096 convex children on a 3 x 3 m heightfield); d = 0.05 + 0.04."""
+    s = M.Scene()
+    rb = pr2_like(s, seed=0, active="fullbody")
+    convex_soup(s, n_hulls=n_hulls, seed=seed, center=(2.05, 0.0))
+    s.finalize(); rb.finalize()
+    return s, rb, static_poses(s), 0.09
+
+
+def fullbody_trajectory(rb, rng, T=100):
+    """Straight line between two seeded configurations: the base creeps along the soup's edge, arms sweep over it."""
+    arm_r, arm_l = rb.q_robot[1:8], rb.q_robot[8:15]
+    q0 = np.concatenate([[0.05], arm_r + rng.uniform(-0.2, 0.2, 7), arm_l + rng.uniform(-0.2, 0.2, 7),
+                         [rng.uniform(-0.35, -0.15), rng.uniform(-0.8, -0.4), rng.uniform(-0.3, 0.3)]])
+    reach_r = np.array([-0.3, 0.2, -0.6, -0.9, -1.0, -0.8, 1.0]) + rng.uniform(-0.3, 0.3, 7)
+    reach_l = np.array([0.3, 0.2, 0.6, -0.9, 1.0, -0.8, -1.0]) + rng.uniform(-0.3, 0.3, 7)
+    q1 = np.concatenate([[0.25], reach_r, reach_l, [rng.uniform(-0.05, 0.1), rng.uniform(0.4, 0.8), rng.uniform(-0.4, 0.4)]])
+    return straight_line(q0, q1, T)
