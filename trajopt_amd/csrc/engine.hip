@@ -1,12 +1,7 @@
 // engine.hip -- libtrajopt_hipcc.so: the C-ABI of include/trajopt_hipcc.h and the gfx950 kernels behind it.
 //
 // Pipeline of one batch call (all on the engine's own stream, nothing allocates after warm-up):
-//   k_fk            dofs[B*T*K] (fp64)            -> link transforms (fp64 quat+trans) + poses of the robot's objects
-//   k_dyn_children  object poses                  -> fp32 3x4 world transform + d-inflated AABB of every moving child
-//   k_broadphase    (set, query child, other child) AABB cull with the reference's filters -> compacted pair list
-//   k_gjk           one group of G lanes per pair: GJK closest points; separated pairs finish here (contact filter,
-//                   cast classification, fused Jacobian epilogue, record write); the rest go to the EPA queue
-//   k_epa           GJK2 + EPA (pools in LDS) for queued pairs, then the same epilogue
+//   k_fk -> k_broadphase -> k_gjk -> k_epa -> k_finish -> k_bump      (kernels and layouts: tohc_kernels.h)
 // Static obstacles are transformed once at upload (the reference re-syncs every object on every call,
 // bullet_collision_checker.cpp:629-655).  See DESIGN.md for layouts and rooflines.
 #include <hip/hip_runtime.h>
@@ -21,455 +16,9 @@
 #include <vector>
 
 #include "../../include/trajopt_hipcc.h"
-#include "tohc_narrow.h"
+#include "tohc_kernels.h"
 
 using namespace tohc;
-
-// -----------------------------------------------------------------------------------------------------------------
-// device views
-// -----------------------------------------------------------------------------------------------------------------
-struct DevScene {
-  int n_shapes, n_children, n_objects;
-  const int *shape_kind, *shape_voff, *shape_vcnt;
-  const float *shape_dims, *shape_lmin, *shape_lmax;  // [n][3]
-  const float *vx, *vy, *vz;
-  const int *child_shape, *child_obj, *child_idx;
-  const float *child_localT;                          // [n][12] rows of the 3x3 then origin
-  const int *obj_off, *obj_cnt, *obj_compound, *obj_group;
-  const unsigned char *allowed;
-  const float *stat_xf;                               // [n_children][12] world transform when the object is static
-  const float *stat_aabb;                             // [n_children][6]
-};
-struct DynMap {          // which objects / children move per set (robot links, or everything in "poses" mode)
-  const int *obj_dyn;    // [n_objects]  -> slot or -1
-  const int *child_dyn;  // [n_children] -> slot or -1
-  int n_dyn_obj, n_dyn_children;
-};
-struct DevRobot {
-  int n_links, K, n_joint_inds, affine;
-  const int *parent, *jtype, *dof, *dof_col, *link_dyn;  // link_dyn: dyn-object slot of the link's geometry or -1
-  const double *T_origin, *axis, *mult, *offs, *q_robot;
-  const int *obj_jaclink;                                // [n_objects] link whose chain gives the Jacobian, or -1
-  double base_T[7];
-  double rot_axis[3];
-};
-struct PairRec { int set, q, x, pad; };
-struct EpaRec { int pair; int isValid; float distance; float n[3]; float pB[3]; };
-struct Counters { unsigned int n_pairs, n_epa, overflow, pad; };  // one per enqueue; the record counter is shared so
-                                                                   // that several enqueues can append to one slab
-
-struct CallParams {
-  int n_cast_sets;   // number of (problem, t) units enumerated
-  int T, gap;        // sets per problem; cast: second pose = set + gap (FK mode) ; poses mode: T = 1, gap = 0
-  int cast;          // 0 discrete, 1 cast
-  int filter_mask;
-  int want_jac;
-  float d, breaking;
-  unsigned int max_pairs, max_records;
-};
-
-__device__ __forceinline__ Xf ldXf(const float *p) {
-  Xf t;
-  t.b.r[0] = mk(p[0], p[1], p[2]);
-  t.b.r[1] = mk(p[3], p[4], p[5]);
-  t.b.r[2] = mk(p[6], p[7], p[8]);
-  t.o = mk(p[9], p[10], p[11]);
-  return t;
-}
-__host__ __device__ __forceinline__ void stXf(float *p, const Xf &t) {
-  for (int i = 0; i < 3; ++i) { p[3 * i] = t.b.r[i].x; p[3 * i + 1] = t.b.r[i].y; p[3 * i + 2] = t.b.r[i].z; }
-  p[9] = t.o.x; p[10] = t.o.y; p[11] = t.o.z;
-}
-__host__ __device__ __forceinline__ Xf ldXfH(const float *p) {
-  Xf t;
-  t.b.r[0] = mk(p[0], p[1], p[2]);
-  t.b.r[1] = mk(p[3], p[4], p[5]);
-  t.b.r[2] = mk(p[6], p[7], p[8]);
-  t.o = mk(p[9], p[10], p[11]);
-  return t;
-}
-
-// -----------------------------------------------------------------------------------------------------------------
-// k_fk: RobotAndDOF::SetDOFValues (configuration_space.cpp:12-23) + link->GetTransform() for every link.
-// One thread per configuration; the chain is walked parents-first, each link reading its parent's result back.
-// -----------------------------------------------------------------------------------------------------------------
-__global__ void k_fk(DevRobot rb, const double *__restrict__ dofs, int n_cfg, double *__restrict__ linkQT, double *__restrict__ objQT,
-                     int n_dyn_obj) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_cfg) return;
-  const double *q = dofs + (size_t)s * rb.K;
-  Dxf base = dxfFrom7(rb.base_T);
-  if (rb.affine) {
-    const double *a = q + rb.n_joint_inds;
-    base.q.w = 1; base.q.x = base.q.y = base.q.z = 0;
-    base.t = mkd(0, 0, 0);
-    if (rb.affine & TOHC_DOF_X) base.t.x = *a++;
-    if (rb.affine & TOHC_DOF_Y) base.t.y = *a++;
-    if (rb.affine & TOHC_DOF_Z) base.t.z = *a++;
-    if (rb.affine & TOHC_DOF_ROTAXIS) {
-      double h = 0.5 * (*a++), sn = sin(h);
-      base.q.w = cos(h);
-      base.q.x = rb.rot_axis[0] * sn; base.q.y = rb.rot_axis[1] * sn; base.q.z = rb.rot_axis[2] * sn;
-    }
-  }
-  double *out = linkQT + (size_t)s * rb.n_links * 7;
-  for (int i = 0; i < rb.n_links; ++i) {
-    Dxf parent = rb.parent[i] < 0 ? base : dxfFrom7(out + 7 * rb.parent[i]);
-    Dxf t = dxfMul(parent, dxfFrom7(rb.T_origin + 7 * i));
-    if (rb.jtype[i] != TOHC_J_FIXED) {
-      double v = rb.offs[i];
-      if (rb.dof[i] >= 0) {
-        double qv = rb.dof_col[i] >= 0 ? q[rb.dof_col[i]] : rb.q_robot[rb.dof[i]];
-        v = rb.mult[i] * qv + rb.offs[i];
-      }
-      D3 ax = mkd(rb.axis[3 * i], rb.axis[3 * i + 1], rb.axis[3 * i + 2]);
-      Dxf m;
-      m.q.w = 1; m.q.x = m.q.y = m.q.z = 0;
-      m.t = mkd(0, 0, 0);
-      if (rb.jtype[i] == TOHC_J_REVOLUTE) {
-        double h = 0.5 * v, sn = sin(h);
-        m.q.w = cos(h); m.q.x = ax.x * sn; m.q.y = ax.y * sn; m.q.z = ax.z * sn;
-      } else {
-        m.t = ax * v;
-      }
-      t = dxfMul(t, m);
-    }
-    dxfTo7(t, out + 7 * i);
-    if (objQT && rb.link_dyn[i] >= 0) dxfTo7(t, objQT + ((size_t)s * n_dyn_obj + rb.link_dyn[i]) * 7);
-  }
-}
-
-// k_dyn_children: object pose (7 doubles) -> fp32 transform exactly as toBt() does, child world transform
-// (orgTrans*childTrans for compounds, btCompoundCollisionAlgorithm.cpp:122-125) and the d-inflated cull box.
-__global__ void k_dyn_children(DevScene sc, DynMap dm, const int *__restrict__ dyn_child_list, const double *__restrict__ objQT,
-                               int n_sets, float d, float *__restrict__ dynXf, float *__restrict__ dynAabb) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t total = (size_t)n_sets * dm.n_dyn_children;
-  if (i >= total) return;
-  int set = (int)(i / dm.n_dyn_children), slot = (int)(i % dm.n_dyn_children);
-  int c = dyn_child_list[slot];
-  int obj = sc.child_obj[c];
-  Xf T = xfFrom7(objQT + ((size_t)set * dm.n_dyn_obj + dm.obj_dyn[obj]) * 7);
-  if (sc.obj_compound[obj]) T = xfMul(T, ldXf(sc.child_localT + 12 * c));
-  stXf(dynXf + i * 12, T);
-  int sh = sc.child_shape[c];
-  Aabb b = shapeAabb(mk(sc.shape_lmin[3 * sh], sc.shape_lmin[3 * sh + 1], sc.shape_lmin[3 * sh + 2]),
-                     mk(sc.shape_lmax[3 * sh], sc.shape_lmax[3 * sh + 1], sc.shape_lmax[3 * sh + 2]), T, d);
-  float *o = dynAabb + i * 6;
-  o[0] = b.lo.x; o[1] = b.lo.y; o[2] = b.lo.z; o[3] = b.hi.x; o[4] = b.hi.y; o[5] = b.hi.z;
-}
-
-__device__ __forceinline__ Aabb ldAabb(const float *p) {
-  Aabb b;
-  b.lo = mk(p[0], p[1], p[2]);
-  b.hi = mk(p[3], p[4], p[5]);
-  return b;
-}
-__device__ __forceinline__ void castSets(const CallParams &cp, int cs, int &set0, int &set1) {
-  int per = cp.cast ? (cp.T - cp.gap) : cp.T;
-  set0 = (cs / per) * cp.T + cs % per;
-  set1 = set0 + (cp.cast ? cp.gap : 0);
-}
-
-// -----------------------------------------------------------------------------------------------------------------
-// k_broadphase: one thread per (unit, query child, other child).  Filters follow CollisionCollector::needsCollision
-// (bullet_collision_checker.cpp:409-413) and btSingleContactCallback::process (btCollisionWorld.cpp:1129-1137); the
-// cull is the engine's own conservative box test (see oracle/trajopt_oracle.c, shapeAabb): both boxes grown by d,
-// closed-interval overlap -- it can never drop a pair whose distance is <= d.
-// -----------------------------------------------------------------------------------------------------------------
-__global__ void k_broadphase(DevScene sc, DynMap dm, CallParams cp, const int *__restrict__ qchildren, int nQ,
-                             const float *__restrict__ dynAabb0, const float *__restrict__ dynAabb1, PairRec *__restrict__ pairs,
-                             Counters *__restrict__ cnt) {
-  const int xTiles = (sc.n_children + blockDim.x - 1) / blockDim.x;
-  const size_t blk = blockIdx.x;
-  const int tile = (int)(blk % xTiles);
-  const size_t uq = blk / xTiles;
-  const int qi = (int)(uq % nQ);
-  const int cs = (int)(uq / nQ);
-  const int x = tile * blockDim.x + threadIdx.x;
-  if (x >= sc.n_children) return;
-  const int q = qchildren[qi];
-  const int Q = sc.child_obj[q], X = sc.child_obj[x];
-  if (Q == X) return;
-  const int gx = sc.obj_group[X];
-  if (cp.cast) {
-    if (!(gx & TOHC_GROUP_KINBODY)) return;  // cc.m_collisionFilterMask = KinBodyFilter (bullet_collision_checker.cpp:983)
-  } else {
-    if (!(gx & (short)cp.filter_mask)) return;
-  }
-  if (!sc.allowed[(size_t)Q * sc.n_objects + X]) return;
-  int set0, set1;
-  castSets(cp, cs, set0, set1);
-  const int qs = dm.child_dyn[q];
-  Aabb bq = qs >= 0 ? ldAabb(dynAabb0 + ((size_t)set0 * dm.n_dyn_children + qs) * 6) : ldAabb(sc.stat_aabb + 6 * q);
-  if (cp.cast && qs >= 0) bq = aabbUnion(bq, ldAabb(dynAabb1 + ((size_t)set1 * dm.n_dyn_children + qs) * 6));
-  const int xs = dm.child_dyn[x];
-  Aabb bx = xs >= 0 ? ldAabb(dynAabb0 + ((size_t)set0 * dm.n_dyn_children + xs) * 6) : ldAabb(sc.stat_aabb + 6 * x);
-  if (!aabbOverlap(bq, bx)) return;
-  unsigned int slot = atomicAdd(&cnt->n_pairs, 1u);
-  if (slot < cp.max_pairs) {
-    PairRec p;
-    p.set = cs; p.q = q; p.x = x; p.pad = 0;
-    pairs[slot] = p;
-  } else {
-    cnt->overflow = 1;
-  }
-}
-
-// -----------------------------------------------------------------------------------------------------------------
-// narrowphase
-// -----------------------------------------------------------------------------------------------------------------
-struct NarrowArgs {
-  DevScene sc;
-  DynMap dm;
-  DevRobot rb;
-  CallParams cp;
-  const float *dynXf0, *dynXf1;
-  const double *linkQT;   // [n_sets][n_links][7], null in poses mode
-  const double *dofs;     // [n_sets][K]
-  const PairRec *pairs;
-  EpaRec *epaq;
-  Counters *cnt;
-  unsigned int *n_records;
-  tohc_record *records;
-  double *grads;          // [max_records][2][K]
-};
-
-template <int G>
-struct PairCtx {
-  Cvx<G> A, B;
-  Xf tA, tB;
-  // bookkeeping for the epilogue
-  int set0, set1, Q, qc, X, xc;
-  bool xIsA;       // X's child is GJK's A (X compound), else the query child is A
-  Xf tf0, tw1;     // cast: pose of the swept child at both ends
-};
-
-template <int G>
-__device__ __forceinline__ void loadShape(const DevScene &sc, int child, Cvx<G> &c) {
-  const int sh = sc.child_shape[child];
-  cvxLoad<G>(c, sc.shape_kind[sh], mk(sc.shape_dims[3 * sh], sc.shape_dims[3 * sh + 1], sc.shape_dims[3 * sh + 2]), sc.vx, sc.vy, sc.vz,
-             sc.shape_voff[sh], sc.shape_vcnt[sh]);
-}
-__device__ __forceinline__ Xf childXf(const NarrowArgs &a, const float *dyn, int set, int child) {
-  const int s = a.dm.child_dyn[child];
-  return s >= 0 ? ldXf(dyn + ((size_t)set * a.dm.n_dyn_children + s) * 12) : ldXf(a.sc.stat_xf + 12 * child);
-}
-
-template <int G>
-__device__ __forceinline__ void setupPair(const NarrowArgs &a, const PairRec &p, PairCtx<G> &c) {
-  castSets(a.cp, p.set, c.set0, c.set1);
-  c.Q = a.sc.child_obj[p.q]; c.X = a.sc.child_obj[p.x];
-  c.qc = a.sc.child_idx[p.q]; c.xc = a.sc.child_idx[p.x];
-  c.xIsA = a.sc.obj_compound[c.X] != 0;
-  Xf tq = childXf(a, a.dynXf0, c.set0, p.q);
-  Xf tx = childXf(a, a.dynXf0, c.set0, p.x);
-  Cvx<G> &cq = c.xIsA ? c.B : c.A;
-  Cvx<G> &cx = c.xIsA ? c.A : c.B;
-  loadShape<G>(a.sc, p.q, cq);
-  loadShape<G>(a.sc, p.x, cx);
-  if (a.cp.cast) {
-    Xf tq1 = childXf(a, a.dynXf1, c.set1, p.q);
-    cq.cast = 1;
-    cq.t01 = xfInverseTimes(tq, tq1);          // CastHullShape(convex, tf0.inverseTimes(tf1)), bullet_collision_checker.cpp:977
-    c.tf0 = tq;
-    c.tw1 = xfMul(tq, cq.t01);                 // m_cow->getWorldTransform() * shape->m_t01, :904
-  }
-  if (c.xIsA) { c.tA = tx; c.tB = tq; } else { c.tA = tq; c.tB = tx; }
-}
-
-// point Jacobian of `link` at world point p, column k: CalculateActiveJacobian as used by PositionJacobian
-// (configuration_space.cpp:83-89).  Chain walked leaf -> root like the oracle, so sums round identically.
-__device__ __forceinline__ D3 jacColumn(const DevRobot &rb, const double *linkQT, const double *q, int link, D3 p, int k) {
-  D3 J = mkd(0, 0, 0);
-  if (k < rb.n_joint_inds) {
-    for (int i = link; i >= 0; i = rb.parent[i]) {
-      if (rb.jtype[i] == TOHC_J_FIXED || rb.dof_col[i] != k) continue;
-      Dxf t = dxfFrom7(linkQT + 7 * i);
-      D3 z = qrot(t.q, mkd(rb.axis[3 * i], rb.axis[3 * i + 1], rb.axis[3 * i + 2]));
-      D3 col = rb.jtype[i] == TOHC_J_REVOLUTE ? cross(z, p - t.t) : z;
-      J.x += rb.mult[i] * col.x; J.y += rb.mult[i] * col.y; J.z += rb.mult[i] * col.z;
-    }
-    return J;
-  }
-  int kk = rb.n_joint_inds;
-  if (rb.affine & TOHC_DOF_X) { if (k == kk) return mkd(1, 0, 0); ++kk; }
-  if (rb.affine & TOHC_DOF_Y) { if (k == kk) return mkd(0, 1, 0); ++kk; }
-  if (rb.affine & TOHC_DOF_Z) { if (k == kk) return mkd(0, 0, 1); ++kk; }
-  if (rb.affine & TOHC_DOF_ROTAXIS) {
-    if (k == kk) {
-      const double *a = q + rb.n_joint_inds;
-      D3 bt = mkd(0, 0, 0);
-      if (rb.affine & TOHC_DOF_X) bt.x = *a++;
-      if (rb.affine & TOHC_DOF_Y) bt.y = *a++;
-      if (rb.affine & TOHC_DOF_Z) bt.z = *a++;
-      return cross(mkd(rb.rot_axis[0], rb.rot_axis[1], rb.rot_axis[2]), p - bt);
-    }
-  }
-  return J;
-}
-
-// CollisionsToDistanceExpressions for one contact at one configuration (collision_terms.cpp:44-56):
-// lanes of the group take the columns k = gl, gl+G, ...; the constant term is summed in column order.
-template <int G>
-__device__ __forceinline__ double linearizeAt(const NarrowArgs &a, int set, int la, int lb, D3 n, D3 ptA, D3 ptB, double dist, double *gradOut) {
-  const DevRobot &rb = a.rb;
-  const int gl = Grp<G>::lane();
-  const double *linkQT = a.linkQT + (size_t)set * rb.n_links * 7;
-  const double *q = a.dofs + (size_t)set * rb.K;
-  double gq = 0;
-  for (int k0 = 0; k0 < rb.K; k0 += G) {
-    const int k = k0 + gl;
-    double g = 0;
-    if (k < rb.K) {
-      if (la >= 0) {
-        D3 J = jacColumn(rb, linkQT, q, la, ptA, k);
-        g += 1.0 * (n.x * J.x + n.y * J.y + n.z * J.z);
-      }
-      if (lb >= 0) {
-        D3 J = jacColumn(rb, linkQT, q, lb, ptB, k);
-        g += -1.0 * (n.x * J.x + n.y * J.y + n.z * J.z);
-      }
-      gradOut[k] = g;
-    }
-    const int lim = min(G, rb.K - k0);
-    for (int j = 0; j < lim; ++j) {
-      double gj = __shfl(g, j, G);
-      gq += gj * q[k0 + j];
-    }
-  }
-  return dist - gq;
-}
-
-// Everything after the narrowphase for one pair: Bullet's output filter, the collector's distance filter, the cast
-// classification, the record and the fused Jacobian rows.
-template <int G>
-__device__ __forceinline__ void finishPair(const NarrowArgs &a, const PairCtx<G> &c, const GjkState &st) {
-  float md2 = a.cp.breaking;
-  md2 *= md2;
-  PairOut o;
-  gjkOutput(st, md2, o);
-  if (!o.valid) return;
-  if ((double)o.distance > (double)a.cp.d) return;  // CollisionCollector::addSingleResult, bullet_collision_checker.cpp:401
-  // btBridgedManifoldResult::addContactPoint (btCollisionWorld.cpp:1068-1086)
-  V3 ptA = o.pointOnB + o.normalOnB * o.distance;
-  V3 ptB = o.pointOnB;
-  V3 nrm = o.normalOnB;
-  int idA = c.xIsA ? c.X : c.Q, chA = c.xIsA ? c.xc : c.qc;
-  int idB = c.xIsA ? c.Q : c.X, chB = c.xIsA ? c.qc : c.xc;
-  int cctype = TOHC_CC_NONE;
-  float time = 0;
-  V3 ptB1 = mk(0, 0, 0);
-  if (a.cp.cast) {
-    const bool castFirst = !c.xIsA;
-    const Cvx<G> &cq = c.xIsA ? c.B : c.A;
-    CastOut co;
-    castClassify<G>(cq, c.tf0, c.tw1, nrm, ptA, ptB, castFirst, co);
-    if (castFirst) {  // swap so that the swept link is B (bullet_collision_checker.cpp:913-917)
-      V3 t = ptA; ptA = ptB; ptB = t;
-      nrm = nrm * -1.0f;
-      int ti = idA; idA = idB; idB = ti;
-      ti = chA; chA = chB; chB = ti;
-    }
-    cctype = co.cctype;
-    time = co.time;
-    if (co.between) { ptB = co.ptB; ptB1 = co.ptB1; }
-  }
-  const int gl = Grp<G>::lane();
-  unsigned int slot = 0;
-  if (gl == 0) slot = atomicAdd(a.n_records, 1u);
-  slot = (unsigned int)__shfl((int)slot, 0, G);
-  if (slot >= a.cp.max_records) {
-    if (gl == 0) a.cnt->overflow = 1;
-    return;
-  }
-  double c0 = 0, c1 = 0;
-  if (a.cp.want_jac && a.linkQT) {
-    const int la = a.rb.obj_jaclink[idA], lb = a.rb.obj_jaclink[idB];
-    D3 n = mkd(nrm.x, nrm.y, nrm.z), pA = mkd(ptA.x, ptA.y, ptA.z), pB = mkd(ptB.x, ptB.y, ptB.z), pB1 = mkd(ptB1.x, ptB1.y, ptB1.z);
-    double *g = a.grads + (size_t)slot * 2 * a.rb.K;
-    c0 = linearizeAt<G>(a, c.set0, la, lb, n, pA, pB, (double)o.distance, g);
-    if (a.cp.cast) {
-      c1 = linearizeAt<G>(a, c.set1, la, lb, n, pA, (cctype == TOHC_CC_BETWEEN) ? pB1 : pB, (double)o.distance, g + a.rb.K);
-    } else {
-      for (int k = gl; k < a.rb.K; k += G) g[a.rb.K + k] = 0;
-    }
-  }
-  if (gl == 0) {
-    tohc_record r;
-    r.problem = c.set0 / a.cp.T;
-    r.t = c.set0 % a.cp.T;
-    r.idA = idA; r.childA = chA; r.idB = idB; r.childB = chB;
-    r.cctype = cctype;
-    r.time = time;
-    r.dist = o.distance;
-    r.n[0] = nrm.x; r.n[1] = nrm.y; r.n[2] = nrm.z;
-    r.ptA[0] = ptA.x; r.ptA[1] = ptA.y; r.ptA[2] = ptA.z;
-    r.ptB[0] = ptB.x; r.ptB[1] = ptB.y; r.ptB[2] = ptB.z;
-    r.ptB1[0] = ptB1.x; r.ptB1[1] = ptB1.y; r.ptB1[2] = ptB1.z;
-    r.const0 = c0; r.const1 = c1;
-    a.records[slot] = r;
-  }
-}
-
-template <int G>
-__global__ void __launch_bounds__(256) k_gjk(NarrowArgs a) {
-  const int groupsPerBlock = blockDim.x / G;
-  const unsigned int gid = blockIdx.x * groupsPerBlock + threadIdx.x / G;
-  const unsigned int ngroups = gridDim.x * groupsPerBlock;
-  unsigned int npairs = a.cnt->n_pairs;
-  if (npairs > a.cp.max_pairs) npairs = a.cp.max_pairs;
-  const int gl = Grp<G>::lane();
-  float md2 = a.cp.breaking;
-  md2 *= md2;
-  for (unsigned int p = gid; p < npairs; p += ngroups) {
-    PairCtx<G> c;
-    setupPair<G>(a, a.pairs[p], c);
-    GjkState st;
-    gjkMain<G>(c.A, c.B, c.tA, c.tB, md2, st);
-    if (st.needEpa) {
-      unsigned int slot = 0;
-      if (gl == 0) {
-        slot = atomicAdd(&a.cnt->n_epa, 1u);
-        EpaRec e;
-        e.pair = (int)p;
-        e.isValid = st.isValid;
-        e.distance = st.distance;
-        e.n[0] = st.normalInB.x; e.n[1] = st.normalInB.y; e.n[2] = st.normalInB.z;
-        e.pB[0] = st.pointOnB.x; e.pB[1] = st.pointOnB.y; e.pB[2] = st.pointOnB.z;
-        a.epaq[slot] = e;   // the queue is as long as the pair list
-      }
-    } else {
-      finishPair<G>(a, c, st);
-    }
-  }
-}
-
-template <int G, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) k_epa(NarrowArgs a) {
-  __shared__ EpaMem mem[BLOCK / G];
-  const int groupsPerBlock = BLOCK / G;
-  const unsigned int gid = blockIdx.x * groupsPerBlock + threadIdx.x / G;
-  const unsigned int ngroups = gridDim.x * groupsPerBlock;
-  unsigned int nepa = a.cnt->n_epa;
-  if (nepa > a.cp.max_pairs) nepa = a.cp.max_pairs;
-  EpaMem *m = &mem[threadIdx.x / G];
-  for (unsigned int i = gid; i < nepa; i += ngroups) {
-    const EpaRec e = a.epaq[i];
-    PairCtx<G> c;
-    setupPair<G>(a, a.pairs[e.pair], c);
-    GjkState st;
-    st.isValid = e.isValid != 0;
-    st.needEpa = true;
-    st.distance = e.distance;
-    st.normalInB = mk(e.n[0], e.n[1], e.n[2]);
-    st.pointOnB = mk(e.pB[0], e.pB[1], e.pB[2]);
-    st.offset = (c.tA.o + c.tB.o) * 0.5f;
-    st.iters = 0;
-    gjkFinishEpa<G>(m, c.A, c.B, c.tA, c.tB, st);
-    finishPair<G>(a, c, st);
-  }
-}
 
 // -----------------------------------------------------------------------------------------------------------------
 // host side
@@ -529,19 +78,26 @@ struct tohc_engine {
   int n_links = 0, K = 0, n_joint_inds = 0, affine = 0, n_dof = 0;
   std::vector<int> h_parent, h_jtype, h_dof, h_dof_col, h_link_obj, h_link_dyn, h_obj_jaclink;
   double base_T[7], rot_axis[3];
-  DBuf<int> d_parent, d_jtype, d_dof, d_dof_col, d_link_dyn, d_obj_jaclink;
+  DBuf<int> d_parent, d_jtype, d_dof, d_dof_col, d_link_dyn, d_obj_jaclink, d_link_obj, d_chain_off, d_chain;
+  std::vector<int> h_chain_off, h_chain;
   DBuf<double> d_T_origin, d_axis, d_mult, d_offs, d_q_robot;
   // dynamic maps: robot mode and all-objects ("poses") mode
   std::vector<int> h_obj_dynR, h_child_dynR, h_dyn_childrenR, h_qchildrenR;
   std::vector<int> h_obj_dynP, h_child_dynP, h_dyn_childrenP;
   DBuf<int> d_obj_dynR, d_child_dynR, d_dyn_childrenR, d_qchildrenR, d_obj_dynP, d_child_dynP, d_dyn_childrenP, d_qchildrenP;
   int n_dyn_objR = 0, n_dyn_childrenR = 0;
+  // children that never move in each mode, with their cull boxes as an SoA table [6][n_stat_pad]
+  std::vector<int> h_stat_childrenR, h_stat_childrenP;
+  DBuf<int> d_stat_childrenR, d_stat_childrenP;
+  DBuf<float> d_stat_soaR, d_stat_soaP;
+  int n_statR = 0, n_stat_padR = 0;
 
   // per-call buffers
   DBuf<double> d_dofs, d_linkQT, d_objQT, d_objQT1, d_grads;
   DBuf<float> d_dynXf, d_dynAabb, d_dynXf1, d_dynAabb1;
   DBuf<PairRec> d_pairs;
   DBuf<EpaRec> d_epaq;
+  DBuf<HitRec> d_hits;
   DBuf<Counters> d_cnt;            // [RING]
   DBuf<tohc_record> d_records;
   HBuf<tohc_record> h_records, h_sorted;
@@ -652,7 +208,7 @@ static int refreshStatic(tohc_engine *e) {
   for (int c = 0; c < e->n_children; ++c) {
     int obj = e->h_child_obj[c];
     Xf T = xfFrom7(&e->h_obj_static_T[7 * obj]);
-    if (e->h_obj_compound[obj]) T = xfMul(T, ldXfH(&e->h_child_localT[12 * c]));
+    if (e->h_obj_compound[obj]) T = xfMul(T, ldXf(&e->h_child_localT[12 * c]));
     stXf(&xf[12 * c], T);
     int sh = e->h_child_shape[c];
     Aabb b = shapeAabb(mk(e->h_shape_lmin[3 * sh], e->h_shape_lmin[3 * sh + 1], e->h_shape_lmin[3 * sh + 2]),
@@ -662,6 +218,15 @@ static int refreshStatic(tohc_engine *e) {
   }
   HIPCHK(upload(e->d_stat_xf, xf, e->stream));
   HIPCHK(upload(e->d_stat_aabb, bb, e->stream));
+  // SoA cull-box table of the children that never move in robot mode (everything until a robot is uploaded)
+  const std::vector<int> &st = e->h_stat_childrenR;
+  e->n_statR = (int)st.size();
+  e->n_stat_padR = (e->n_statR + 63) / 64 * 64 + 64;
+  std::vector<float> soa((size_t)6 * e->n_stat_padR, 0.f);
+  for (int i = 0; i < e->n_statR; ++i)
+    for (int k = 0; k < 6; ++k) soa[(size_t)k * e->n_stat_padR + i] = bb[6 * (size_t)st[i] + k];
+  HIPCHK(upload(e->d_stat_soaR, soa, e->stream));
+  HIPCHK(upload(e->d_stat_childrenR, st.empty() ? std::vector<int>(1, 0) : st, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   return TOHC_OK;
 }
@@ -731,6 +296,8 @@ int tohc_upload_scene(tohc_engine *e, int n_shapes, const int32_t *shape_kind, c
   e->h_obj_dynP.resize(n_objects); std::iota(e->h_obj_dynP.begin(), e->h_obj_dynP.end(), 0);
   e->h_child_dynP.resize(n_children); std::iota(e->h_child_dynP.begin(), e->h_child_dynP.end(), 0);
   e->h_dyn_childrenP = e->h_child_dynP;
+  e->h_stat_childrenR = e->h_child_dynP;   // no robot yet: nothing moves in robot mode
+  e->h_stat_childrenP.clear();
   hipStream_t s = e->stream;
   HIPCHK(upload(e->d_shape_kind, e->h_shape_kind, s)); HIPCHK(upload(e->d_shape_voff, e->h_shape_voff, s)); HIPCHK(upload(e->d_shape_vcnt, e->h_shape_vcnt, s));
   HIPCHK(upload(e->d_shape_dims, e->h_shape_dims, s)); HIPCHK(upload(e->d_shape_lmin, e->h_shape_lmin, s)); HIPCHK(upload(e->d_shape_lmax, e->h_shape_lmax, s));
@@ -746,6 +313,7 @@ int tohc_upload_scene(tohc_engine *e, int n_shapes, const int32_t *shape_kind, c
   HIPCHK(upload(e->d_obj_off, e->h_obj_off, s)); HIPCHK(upload(e->d_obj_cnt, e->h_obj_cnt, s)); HIPCHK(upload(e->d_obj_compound, e->h_obj_compound, s));
   HIPCHK(upload(e->d_obj_group, e->h_obj_group, s)); HIPCHK(upload(e->d_allowed, e->h_allowed, s));
   HIPCHK(upload(e->d_obj_dynP, e->h_obj_dynP, s)); HIPCHK(upload(e->d_child_dynP, e->h_child_dynP, s)); HIPCHK(upload(e->d_dyn_childrenP, e->h_dyn_childrenP, s));
+  HIPCHK(upload(e->d_stat_childrenP, std::vector<int>(1, 0), s)); HIPCHK(upload(e->d_stat_soaP, std::vector<float>(6 * 64, 0.f), s));
   HIPCHK(hipStreamSynchronize(s));
   e->have_scene = true;
   e->have_robot = false;
@@ -800,9 +368,21 @@ int tohc_upload_robot(tohc_engine *e, int n_links, const int32_t *parent, const 
     if (affected) e->h_obj_jaclink[o] = i;
   }
   e->n_dyn_objR = nd; e->n_dyn_childrenR = (int)e->h_dyn_childrenR.size();
+  e->h_stat_childrenR.clear();
+  for (int c = 0; c < e->n_children; ++c)
+    if (e->h_child_dynR[c] < 0) e->h_stat_childrenR.push_back(c);
+  // ancestors of each link, root first (k_fk composes every chain in that order)
+  e->h_chain_off.assign(n_links + 1, 0); e->h_chain.clear();
+  for (int i = 0; i < n_links; ++i) {
+    std::vector<int> up;
+    for (int j = i; j >= 0; j = parent[j]) up.push_back(j);
+    for (auto it = up.rbegin(); it != up.rend(); ++it) e->h_chain.push_back(*it);
+    e->h_chain_off[i + 1] = (int)e->h_chain.size();
+  }
   hipStream_t s = e->stream;
   HIPCHK(upload(e->d_parent, e->h_parent, s)); HIPCHK(upload(e->d_jtype, e->h_jtype, s)); HIPCHK(upload(e->d_dof, e->h_dof, s));
   HIPCHK(upload(e->d_dof_col, e->h_dof_col, s)); HIPCHK(upload(e->d_link_dyn, e->h_link_dyn, s)); HIPCHK(upload(e->d_obj_jaclink, e->h_obj_jaclink, s));
+  HIPCHK(upload(e->d_link_obj, e->h_link_obj, s)); HIPCHK(upload(e->d_chain_off, e->h_chain_off, s)); HIPCHK(upload(e->d_chain, e->h_chain, s));
   HIPCHK(upload(e->d_T_origin, T_origin, (size_t)7 * n_links, s)); HIPCHK(upload(e->d_axis, axis, (size_t)3 * n_links, s));
   HIPCHK(upload(e->d_mult, mult, (size_t)n_links, s)); HIPCHK(upload(e->d_offs, offs, (size_t)n_links, s));
   {
@@ -815,7 +395,7 @@ int tohc_upload_robot(tohc_engine *e, int n_links, const int32_t *parent, const 
   HIPCHK(upload(e->d_dyn_childrenR, e->h_dyn_childrenR, s)); HIPCHK(upload(e->d_qchildrenR, e->h_qchildrenR, s));
   HIPCHK(hipStreamSynchronize(s));
   e->have_robot = true;
-  return TOHC_OK;
+  return refreshStatic(e);
 }
 
 int tohc_set_allowed_matrix(tohc_engine *e, int n_objects, const uint8_t *allowed) {
@@ -872,10 +452,25 @@ static DevRobot devRobot(tohc_engine *e) {
   r.n_links = e->n_links; r.K = e->K; r.n_joint_inds = e->n_joint_inds; r.affine = e->affine;
   r.parent = e->d_parent.p; r.jtype = e->d_jtype.p; r.dof = e->d_dof.p; r.dof_col = e->d_dof_col.p; r.link_dyn = e->d_link_dyn.p;
   r.T_origin = e->d_T_origin.p; r.axis = e->d_axis.p; r.mult = e->d_mult.p; r.offs = e->d_offs.p; r.q_robot = e->d_q_robot.p;
-  r.obj_jaclink = e->d_obj_jaclink.p;
+  r.obj_jaclink = e->d_obj_jaclink.p; r.link_obj = e->d_link_obj.p; r.chain_off = e->d_chain_off.p; r.chain = e->d_chain.p;
   memcpy(r.base_T, e->base_T, sizeof r.base_T);
   memcpy(r.rot_axis, e->rot_axis, sizeof r.rot_axis);
   return r;
+}
+
+static DynMap dynMapRobot(tohc_engine *e) {
+  DynMap dm;
+  dm.obj_dyn = e->d_obj_dynR.p; dm.child_dyn = e->d_child_dynR.p; dm.n_dyn_obj = e->n_dyn_objR; dm.n_dyn_children = e->n_dyn_childrenR;
+  dm.dyn_children = e->d_dyn_childrenR.p; dm.stat_children = e->d_stat_childrenR.p; dm.stat_soa = e->d_stat_soaR.p;
+  dm.n_stat = e->n_statR; dm.n_stat_pad = e->n_stat_padR;
+  return dm;
+}
+static DynMap dynMapPoses(tohc_engine *e) {
+  DynMap dm;
+  dm.obj_dyn = e->d_obj_dynP.p; dm.child_dyn = e->d_child_dynP.p; dm.n_dyn_obj = e->n_objects; dm.n_dyn_children = e->n_children;
+  dm.dyn_children = e->d_dyn_childrenP.p; dm.stat_children = e->d_stat_childrenP.p; dm.stat_soa = e->d_stat_soaP.p;
+  dm.n_stat = 0; dm.n_stat_pad = 64;
+  return dm;
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -894,10 +489,16 @@ static int syncEngine(tohc_engine *e) {
   c.ms_last_call = 0;
   for (const auto &pd : e->pending) {
     const Counters &k = e->h_cnt.p[pd.slot];
-    overflow |= k.overflow != 0 || k.n_pairs > e->max_pairs;
-    worst_pairs = std::max(worst_pairs, k.n_pairs);
-    c.aabb_tests += pd.aabb_tests; c.pair_evals += k.n_pairs; c.epa_evals += k.n_epa;
-    c.cum_aabb_tests += pd.aabb_tests; c.cum_pair_evals += k.n_pairs; c.cum_epa_evals += k.n_epa;
+    const unsigned int segCap = (unsigned int)(e->max_pairs / TOHC_NSHARD);
+    unsigned int np = 0, ne = 0;
+    overflow |= k.overflow != 0;
+    for (int sh = 0; sh < TOHC_NSHARD; ++sh) {
+      overflow |= k.n_pairs[sh] > segCap || k.n_epa[sh] > segCap || k.n_hits[sh] > segCap;
+      np += k.n_pairs[sh]; ne += k.n_epa[sh];
+    }
+    worst_pairs = std::max(worst_pairs, np);
+    c.aabb_tests += pd.aabb_tests; c.pair_evals += np; c.epa_evals += ne;
+    c.cum_aabb_tests += pd.aabb_tests; c.cum_pair_evals += np; c.cum_epa_evals += ne;
     float ms[5] = {0, 0, 0, 0, 0};
     hipEvent_t *ev = &e->events[(size_t)pd.slot * 6];
     for (int i = 0; i < 5; ++i) HIPCHK(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
@@ -909,7 +510,7 @@ static int syncEngine(tohc_engine *e) {
   const unsigned int nrec = *e->h_nrec.p;
   c.contacts = nrec;
   if (overflow || nrec > e->max_records)
-    return fail(e, TOHC_E_CAPACITY, "capacity exceeded: %u pairs in one enqueue (max %zu), %u records (max %zu); raise with tohc_set_capacity",
+    return fail(e, TOHC_E_CAPACITY, "capacity exceeded: %u pairs in one enqueue (max %zu, split over 16 shards), %u records (max %zu); raise with tohc_set_capacity",
                 worst_pairs, e->max_pairs, nrec, e->max_records);
   return TOHC_OK;
 }
@@ -939,19 +540,18 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
   hipEvent_t *ev = &e->events[(size_t)slot * 6];
   HIPCHK(hipMemsetAsync(e->d_cnt.p + slot, 0, sizeof(Counters), s));
   if (!append) HIPCHK(hipMemsetAsync(e->d_nrec.p, 0, sizeof(unsigned int), s));
-  cp.max_pairs = (unsigned int)e->max_pairs; cp.max_records = (unsigned int)e->max_records;
-  HIPCHK(e->d_pairs.reserve(e->max_pairs)); HIPCHK(e->d_epaq.reserve(e->max_pairs));
+  cp.seg_cap = (unsigned int)(e->max_pairs / TOHC_NSHARD); cp.max_records = (unsigned int)e->max_records;
+  const size_t qcap = (size_t)cp.seg_cap * TOHC_NSHARD;
+  HIPCHK(e->d_pairs.reserve(qcap)); HIPCHK(e->d_epaq.reserve(qcap)); HIPCHK(e->d_hits.reserve(qcap));
   HIPCHK(e->d_records.reserve(e->max_records));
   HIPCHK(e->d_grads.reserve(e->max_records * 2 * (size_t)K));
   HIPCHK(hipEventRecord(ev[2], s));
   if (nQ > 0 && cp.n_cast_sets > 0) {
     DevScene sc = devScene(e);
-    const int BT = 256;
-    const int xTiles = (e->n_children + BT - 1) / BT;
-    const size_t blocks = (size_t)cp.n_cast_sets * nQ * xTiles;
+    const size_t blocks = (size_t)cp.n_cast_sets * nQ;
     if (blocks > 0x7fffffffull) return fail(e, TOHC_E_CAPACITY, "broadphase grid too large (%zu blocks)", blocks);
     const bool sep1 = cp.gap == 0 && cp.cast;  // poses mode keeps the end-of-sweep poses in their own tables
-    hipLaunchKernelGGL(k_broadphase, dim3((unsigned)blocks), dim3(BT), 0, s, sc, dm, cp, d_qchildren, nQ, e->d_dynAabb.p,
+    hipLaunchKernelGGL(k_broadphase, dim3((unsigned)blocks), dim3(TOHC_BP_THREADS), 0, s, sc, dm, cp, d_qchildren, nQ, e->d_dynAabb.p,
                        sep1 ? e->d_dynAabb1.p : e->d_dynAabb.p, e->d_pairs.p, e->d_cnt.p + slot);
     HIPCHK(hipEventRecord(ev[3], s));
     NarrowArgs a;
@@ -959,7 +559,7 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
     a.dynXf0 = e->d_dynXf.p; a.dynXf1 = sep1 ? e->d_dynXf1.p : e->d_dynXf.p;
     a.linkQT = robotMode ? e->d_linkQT.p : nullptr;
     a.dofs = robotMode ? e->d_dofs.p : nullptr;
-    a.pairs = e->d_pairs.p; a.epaq = e->d_epaq.p; a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p;
+    a.pairs = e->d_pairs.p; a.epaq = e->d_epaq.p; a.hits = e->d_hits.p; a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p;
     a.records = e->d_records.p; a.grads = e->d_grads.p;
     const int gridN = 256 * 8;
     if (e->group == 64) hipLaunchKernelGGL((k_gjk<64>), dim3(gridN), dim3(256), 0, s, a);
@@ -967,6 +567,9 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
     HIPCHK(hipEventRecord(ev[4], s));
     if (e->group == 64) hipLaunchKernelGGL((k_epa<64, 64>), dim3(gridN), dim3(64), 0, s, a);
     else hipLaunchKernelGGL((k_epa<16, 64>), dim3(gridN), dim3(64), 0, s, a);
+    if (e->group == 64) hipLaunchKernelGGL((k_finish<64>), dim3(256 * 2), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_finish<16>), dim3(256 * 2), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, s, e->d_cnt.p + slot, cp.seg_cap, e->d_nrec.p);
     HIPCHK(hipEventRecord(ev[5], s));
     HIPCHK(hipGetLastError());
   } else {
@@ -1019,15 +622,10 @@ static int enqueueRobot(tohc_engine *e, int gap, int cast, int filter_mask, int 
   hipStream_t s = e->stream;
   hipEvent_t *ev = &e->events[(size_t)slot * 6];
   HIPCHK(hipEventRecord(ev[0], s));
-  hipLaunchKernelGGL(k_fk, dim3((unsigned)((n_sets + 63) / 64)), dim3(64), 0, s, devRobot(e), e->d_dofs.p, (int)n_sets, e->d_linkQT.p, e->d_objQT.p,
-                     e->n_dyn_objR);
+  DynMap dm = dynMapRobot(e);
+  hipLaunchKernelGGL(k_fk, dim3((unsigned)n_sets), dim3(64), (size_t)e->n_links * 7 * sizeof(double), s, devRobot(e), devScene(e), dm, e->d_dofs.p,
+                     (int)n_sets, e->d, e->d_linkQT.p, e->d_objQT.p, e->d_dynXf.p, e->d_dynAabb.p);
   HIPCHK(hipEventRecord(ev[1], s));
-  DynMap dm;
-  dm.obj_dyn = e->d_obj_dynR.p; dm.child_dyn = e->d_child_dynR.p; dm.n_dyn_obj = e->n_dyn_objR; dm.n_dyn_children = e->n_dyn_childrenR;
-  const size_t tot = n_sets * e->n_dyn_childrenR;
-  if (tot > 0)
-    hipLaunchKernelGGL(k_dyn_children, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, devScene(e), dm, e->d_dyn_childrenR.p, e->d_objQT.p,
-                       (int)n_sets, e->d, e->d_dynXf.p, e->d_dynAabb.p);
   CallParams cp;
   memset(&cp, 0, sizeof cp);
   cp.T = T; cp.gap = cast ? gap : 0; cp.cast = cast; cp.filter_mask = filter_mask; cp.want_jac = want_jac; cp.d = e->d; cp.breaking = e->breaking;
@@ -1139,10 +737,9 @@ static int posesQuery(tohc_engine *e, const double *obj_T, const double *cast_T1
   HIPCHK(upload(e->d_objQT, obj_T, (size_t)n_sets * nobj * 7, s));
   HIPCHK(upload(e->d_qchildrenP, qch, s));
   HIPCHK(e->d_dynXf.reserve((size_t)n_sets * nch * 12)); HIPCHK(e->d_dynAabb.reserve((size_t)n_sets * nch * 6));
-  DynMap dm;
-  dm.obj_dyn = e->d_obj_dynP.p; dm.child_dyn = e->d_child_dynP.p; dm.n_dyn_obj = (int)nobj; dm.n_dyn_children = (int)nch;
+  DynMap dm = dynMapPoses(e);
   const size_t tot = (size_t)n_sets * nch;
-  hipLaunchKernelGGL(k_dyn_children, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, devScene(e), dm, e->d_dyn_childrenP.p, e->d_objQT.p, n_sets,
+  hipLaunchKernelGGL(k_dyn_children, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, devScene(e), dm, e->d_objQT.p, n_sets,
                      e->d, e->d_dynXf.p, e->d_dynAabb.p);
   std::vector<double> T1;
   if (cast) {
@@ -1152,7 +749,7 @@ static int posesQuery(tohc_engine *e, const double *obj_T, const double *cast_T1
       for (int i = 0; i < n_query; ++i) memcpy(&T1[((size_t)st * nobj + query[i]) * 7], cast_T1 + ((size_t)st * n_query + i) * 7, 7 * sizeof(double));
     HIPCHK(upload(e->d_objQT1, T1, s));
     HIPCHK(e->d_dynXf1.reserve((size_t)n_sets * nch * 12)); HIPCHK(e->d_dynAabb1.reserve((size_t)n_sets * nch * 6));
-    hipLaunchKernelGGL(k_dyn_children, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, devScene(e), dm, e->d_dyn_childrenP.p, e->d_objQT1.p,
+    hipLaunchKernelGGL(k_dyn_children, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, devScene(e), dm, e->d_objQT1.p,
                        n_sets, e->d, e->d_dynXf1.p, e->d_dynAabb1.p);
   }
   HIPCHK(hipStreamSynchronize(s));  // caller-owned / local host buffers may go away
@@ -1186,7 +783,8 @@ int tohc_forward_kinematics(tohc_engine *e, const double *dofs, int n_cfg, doubl
   hipStream_t s = e->stream;
   HIPCHK(upload(e->d_dofs, dofs, (size_t)n_cfg * e->K, s));
   HIPCHK(e->d_linkQT.reserve((size_t)n_cfg * e->n_links * 7));
-  hipLaunchKernelGGL(k_fk, dim3((unsigned)((n_cfg + 63) / 64)), dim3(64), 0, s, devRobot(e), e->d_dofs.p, n_cfg, e->d_linkQT.p, (double *)nullptr, 0);
+  hipLaunchKernelGGL(k_fk, dim3((unsigned)n_cfg), dim3(64), (size_t)e->n_links * 7 * sizeof(double), s, devRobot(e), devScene(e), dynMapRobot(e),
+                     e->d_dofs.p, n_cfg, e->d, e->d_linkQT.p, (double *)nullptr, (float *)nullptr, (float *)nullptr);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(link_T, e->d_linkQT.p, (size_t)n_cfg * e->n_links * 7 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));

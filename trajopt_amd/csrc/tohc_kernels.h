@@ -1,0 +1,604 @@
+// tohc_kernels.h -- device-side data views and the gfx950 kernels of the collision-linearization engine.
+//
+//   k_fk            one 64-thread block per configuration: joint motions in parallel, then every link composes its own
+//                   chain root-first (same association as a serial walk, so results equal the serial oracle bit for
+//                   bit); the same thread emits the fp32 pose + d-inflated cull box of the link's geometry
+//   k_dyn_children  "poses" mode only: object poses given by the caller -> child poses + cull boxes
+//   k_broadphase    one block per (unit, query child): streams the SoA box table of the static children (coalesced),
+//                   queues hits in LDS and reserves space in the pair list with ONE atomic per flush, on one of
+//                   NSHARD counters (a single word saturates at ~88 atomics/us, MI355X_MICROARCH.md "dequeue")
+//   k_gjk           one group of G lanes per pair: GJK closest points (tohc_narrow.h); separated pairs that pass the
+//                   contact filter go to the hit list, penetrating / degenerate ones to the EPA queue
+//   k_epa           GJK2 + EPA with pools in LDS for the queued pairs -> hit list
+//   k_finish        one group per hit: cast classification, record write, fused Jacobian rows (fp64); the p-th hit
+//                   becomes record base+p, so no atomics here
+// All queues are sharded NSHARD ways by producer block; consumers walk them through a 16-entry prefix.
+#pragma once
+#include "../../include/trajopt_hipcc.h"
+#include "tohc_narrow.h"
+
+namespace tohc {
+
+#define TOHC_NSHARD 16
+
+struct DevScene {
+  int n_shapes, n_children, n_objects;
+  const int *shape_kind, *shape_voff, *shape_vcnt;
+  const float *shape_dims, *shape_lmin, *shape_lmax;  // [n][3]
+  const float *vx, *vy, *vz;
+  const int *child_shape, *child_obj, *child_idx;
+  const float *child_localT;                          // [n][12] rows of the 3x3 then origin
+  const int *obj_off, *obj_cnt, *obj_compound, *obj_group;
+  const unsigned char *allowed;
+  const float *stat_xf;                               // [n_children][12] world transform when the object is static
+  const float *stat_aabb;                             // [n_children][6]
+};
+struct DynMap {          // which objects / children move per set (robot links, or everything in "poses" mode)
+  const int *obj_dyn;    // [n_objects]  -> slot or -1
+  const int *child_dyn;  // [n_children] -> slot or -1
+  int n_dyn_obj, n_dyn_children;
+  const int *dyn_children;   // [n_dyn_children] child ids
+  const int *stat_children;  // [n_stat] child ids that never move in this mode
+  const float *stat_soa;     // [6][n_stat_pad] their cull boxes, SoA
+  int n_stat, n_stat_pad;
+};
+struct DevRobot {
+  int n_links, K, n_joint_inds, affine;
+  const int *parent, *jtype, *dof, *dof_col, *link_dyn, *link_obj;
+  const int *chain_off, *chain;                          // ancestors of each link, root first, the link itself last
+  const double *T_origin, *axis, *mult, *offs, *q_robot;
+  const int *obj_jaclink;                                // [n_objects] link whose chain gives the Jacobian, or -1
+  double base_T[7];
+  double rot_axis[3];
+};
+struct PairRec { int set, q, x, pad; };
+struct EpaRec { int pair; int isValid; float distance; float n[3]; float pB[3]; };
+struct HitRec { int pair; float distance; float n[3]; float pB[3]; };
+struct Counters {  // one per enqueue
+  unsigned int n_pairs[TOHC_NSHARD], n_epa[TOHC_NSHARD], n_hits[TOHC_NSHARD];
+  unsigned int overflow, pad[15];
+};
+
+struct CallParams {
+  int n_cast_sets;   // number of (problem, t) units enumerated
+  int T, gap;        // sets per problem; cast: second pose = set + gap (robot mode); poses mode: T = 1, gap = 0
+  int cast;          // 0 discrete, 1 cast
+  int filter_mask;
+  int want_jac;
+  float d, breaking;
+  unsigned int seg_cap;      // capacity of ONE shard of the pair / EPA / hit queues
+  unsigned int max_records;
+};
+
+__host__ __device__ __forceinline__ Xf ldXf(const float *p) {
+  Xf t;
+  t.b.r[0] = mk(p[0], p[1], p[2]);
+  t.b.r[1] = mk(p[3], p[4], p[5]);
+  t.b.r[2] = mk(p[6], p[7], p[8]);
+  t.o = mk(p[9], p[10], p[11]);
+  return t;
+}
+__host__ __device__ __forceinline__ void stXf(float *p, const Xf &t) {
+  for (int i = 0; i < 3; ++i) { p[3 * i] = t.b.r[i].x; p[3 * i + 1] = t.b.r[i].y; p[3 * i + 2] = t.b.r[i].z; }
+  p[9] = t.o.x; p[10] = t.o.y; p[11] = t.o.z;
+}
+__device__ __forceinline__ Aabb ldAabb(const float *p) {
+  Aabb b;
+  b.lo = mk(p[0], p[1], p[2]);
+  b.hi = mk(p[3], p[4], p[5]);
+  return b;
+}
+__device__ __forceinline__ void castSets(const CallParams &cp, int cs, int &set0, int &set1) {
+  int per = cp.cast ? (cp.T - cp.gap) : cp.T;
+  set0 = (cs / per) * cp.T + cs % per;
+  set1 = set0 + (cp.cast ? cp.gap : 0);
+}
+
+// ---- sharded queues ---------------------------------------------------------------------------------------------
+struct QPrefix {
+  unsigned int start[TOHC_NSHARD + 1];
+};
+__device__ __forceinline__ void qprefix(const unsigned int *counts, unsigned int segCap, QPrefix &p) {
+  unsigned int acc = 0;
+#pragma unroll
+  for (int i = 0; i < TOHC_NSHARD; ++i) {
+    p.start[i] = acc;
+    unsigned int c = counts[i];
+    acc += c < segCap ? c : segCap;
+  }
+  p.start[TOHC_NSHARD] = acc;
+}
+// logical index -> physical position (shard * segCap + offset)
+__device__ __forceinline__ unsigned int qlocate(const QPrefix &p, unsigned int segCap, unsigned int i) {
+  unsigned int sh = 0;
+#pragma unroll
+  for (int k = 1; k < TOHC_NSHARD; ++k) sh += (i >= p.start[k]) ? 1u : 0u;
+  unsigned int st = p.start[0];
+#pragma unroll
+  for (int k = 1; k < TOHC_NSHARD; ++k)
+    if (k == (int)sh) st = p.start[k];
+  return sh * segCap + (i - st);
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// k_fk: RobotAndDOF::SetDOFValues (configuration_space.cpp:12-23) + link->GetTransform() for every link, plus what
+// UpdateBulletFromRave / updateAabbs do for the robot's links (bullet_collision_checker.cpp:648-653).
+// -----------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_fk(DevRobot rb, DevScene sc, DynMap dm, const double *__restrict__ dofs, int n_cfg, float d,
+                                           double *__restrict__ linkQT, double *__restrict__ objQT, float *__restrict__ dynXf,
+                                           float *__restrict__ dynAabb) {
+  extern __shared__ double s_motion[];  // [n_links][7]
+  const int s = blockIdx.x;
+  if (s >= n_cfg) return;
+  const double *q = dofs + (size_t)s * rb.K;
+  for (int i = threadIdx.x; i < rb.n_links; i += blockDim.x) {
+    Dxf m;
+    m.q.w = 1; m.q.x = m.q.y = m.q.z = 0;
+    m.t = mkd(0, 0, 0);
+    if (rb.jtype[i] != TOHC_J_FIXED) {
+      double v = rb.offs[i];
+      if (rb.dof[i] >= 0) {
+        double qv = rb.dof_col[i] >= 0 ? q[rb.dof_col[i]] : rb.q_robot[rb.dof[i]];
+        v = rb.mult[i] * qv + rb.offs[i];
+      }
+      D3 ax = mkd(rb.axis[3 * i], rb.axis[3 * i + 1], rb.axis[3 * i + 2]);
+      if (rb.jtype[i] == TOHC_J_REVOLUTE) {
+        double h = 0.5 * v, sn = sin(h);
+        m.q.w = cos(h); m.q.x = ax.x * sn; m.q.y = ax.y * sn; m.q.z = ax.z * sn;
+      } else {
+        m.t = ax * v;
+      }
+    }
+    dxfTo7(m, s_motion + 7 * i);
+  }
+  __syncthreads();
+  Dxf base = dxfFrom7(rb.base_T);
+  if (rb.affine) {
+    const double *a = q + rb.n_joint_inds;
+    base.q.w = 1; base.q.x = base.q.y = base.q.z = 0;
+    base.t = mkd(0, 0, 0);
+    if (rb.affine & TOHC_DOF_X) base.t.x = *a++;
+    if (rb.affine & TOHC_DOF_Y) base.t.y = *a++;
+    if (rb.affine & TOHC_DOF_Z) base.t.z = *a++;
+    if (rb.affine & TOHC_DOF_ROTAXIS) {
+      double h = 0.5 * (*a++), sn = sin(h);
+      base.q.w = cos(h);
+      base.q.x = rb.rot_axis[0] * sn; base.q.y = rb.rot_axis[1] * sn; base.q.z = rb.rot_axis[2] * sn;
+    }
+  }
+  for (int i = threadIdx.x; i < rb.n_links; i += blockDim.x) {
+    Dxf t = base;
+    for (int c = rb.chain_off[i]; c < rb.chain_off[i + 1]; ++c) {
+      const int a = rb.chain[c];
+      t = dxfMul(t, dxfFrom7(rb.T_origin + 7 * a));
+      if (rb.jtype[a] != TOHC_J_FIXED) t = dxfMul(t, dxfFrom7(s_motion + 7 * a));
+    }
+    double t7[7];
+    dxfTo7(t, t7);
+    double *out = linkQT + ((size_t)s * rb.n_links + i) * 7;
+    for (int k = 0; k < 7; ++k) out[k] = t7[k];
+    const int slot = rb.link_dyn[i];
+    if (objQT && slot >= 0) {
+      double *oo = objQT + ((size_t)s * dm.n_dyn_obj + slot) * 7;
+      for (int k = 0; k < 7; ++k) oo[k] = t7[k];
+      // the link's geometry: fp32 pose exactly as toBt() makes it, child poses, cull boxes
+      const int obj = rb.link_obj[i];
+      const Xf T = xfFrom7(t7);
+      for (int k = 0; k < sc.obj_cnt[obj]; ++k) {
+        const int c = sc.obj_off[obj] + k;
+        Xf Tc = T;
+        if (sc.obj_compound[obj]) Tc = xfMul(T, ldXf(sc.child_localT + 12 * c));
+        const size_t o = (size_t)s * dm.n_dyn_children + dm.child_dyn[c];
+        stXf(dynXf + o * 12, Tc);
+        const int sh = sc.child_shape[c];
+        Aabb b = shapeAabb(mk(sc.shape_lmin[3 * sh], sc.shape_lmin[3 * sh + 1], sc.shape_lmin[3 * sh + 2]),
+                           mk(sc.shape_lmax[3 * sh], sc.shape_lmax[3 * sh + 1], sc.shape_lmax[3 * sh + 2]), Tc, d);
+        float *ob = dynAabb + o * 6;
+        ob[0] = b.lo.x; ob[1] = b.lo.y; ob[2] = b.lo.z; ob[3] = b.hi.x; ob[4] = b.hi.y; ob[5] = b.hi.z;
+      }
+    }
+  }
+}
+
+// k_dyn_children ("poses" mode): object pose (7 doubles) -> fp32 transform exactly as toBt() does, child world
+// transform (orgTrans*childTrans for compounds, btCompoundCollisionAlgorithm.cpp:122-125) and the cull box.
+__global__ void k_dyn_children(DevScene sc, DynMap dm, const double *__restrict__ objQT, int n_sets, float d, float *__restrict__ dynXf,
+                               float *__restrict__ dynAabb) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)n_sets * dm.n_dyn_children;
+  if (i >= total) return;
+  int set = (int)(i / dm.n_dyn_children), slot = (int)(i % dm.n_dyn_children);
+  int c = dm.dyn_children[slot];
+  int obj = sc.child_obj[c];
+  Xf T = xfFrom7(objQT + ((size_t)set * dm.n_dyn_obj + dm.obj_dyn[obj]) * 7);
+  if (sc.obj_compound[obj]) T = xfMul(T, ldXf(sc.child_localT + 12 * c));
+  stXf(dynXf + i * 12, T);
+  int sh = sc.child_shape[c];
+  Aabb b = shapeAabb(mk(sc.shape_lmin[3 * sh], sc.shape_lmin[3 * sh + 1], sc.shape_lmin[3 * sh + 2]),
+                     mk(sc.shape_lmax[3 * sh], sc.shape_lmax[3 * sh + 1], sc.shape_lmax[3 * sh + 2]), T, d);
+  float *o = dynAabb + i * 6;
+  o[0] = b.lo.x; o[1] = b.lo.y; o[2] = b.lo.z; o[3] = b.hi.x; o[4] = b.hi.y; o[5] = b.hi.z;
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// k_broadphase: filters follow CollisionCollector::needsCollision (bullet_collision_checker.cpp:409-413) and
+// btSingleContactCallback::process (btCollisionWorld.cpp:1129-1137); the cull is the engine's own conservative box
+// test (same arithmetic as oracle/trajopt_oracle.c shapeAabb): both boxes grown by d, closed-interval overlap -- it
+// can never drop a pair whose distance is <= d.
+// -----------------------------------------------------------------------------------------------------------------
+#define TOHC_BP_THREADS 256
+#define TOHC_BP_CHUNK 2048
+__global__ void __launch_bounds__(TOHC_BP_THREADS) k_broadphase(DevScene sc, DynMap dm, CallParams cp, const int *__restrict__ qchildren, int nQ,
+                                                                const float *__restrict__ dynAabb0, const float *__restrict__ dynAabb1,
+                                                                PairRec *__restrict__ pairs, Counters *__restrict__ cnt) {
+  __shared__ int s_hits[TOHC_BP_CHUNK];
+  __shared__ unsigned int s_n, s_base;
+  const int qi = blockIdx.x % nQ;
+  const int cs = blockIdx.x / nQ;
+  const int q = qchildren[qi];
+  const int Q = sc.child_obj[q];
+  const int shard = blockIdx.x % TOHC_NSHARD;
+  int set0, set1;
+  castSets(cp, cs, set0, set1);
+  const int qs = dm.child_dyn[q];
+  Aabb bq = qs >= 0 ? ldAabb(dynAabb0 + ((size_t)set0 * dm.n_dyn_children + qs) * 6) : ldAabb(sc.stat_aabb + 6 * q);
+  if (cp.cast && qs >= 0) bq = aabbUnion(bq, ldAabb(dynAabb1 + ((size_t)set1 * dm.n_dyn_children + qs) * 6));
+  const unsigned char *allowedRow = sc.allowed + (size_t)Q * sc.n_objects;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  // two passes: children that never move (SoA table, coalesced), then the moving ones (robot links / everything)
+  for (int pass = 0; pass < 2; ++pass) {
+    const int n = pass == 0 ? dm.n_stat : dm.n_dyn_children;
+    for (int base = 0; base < n; base += TOHC_BP_CHUNK) {
+      for (int i = base + threadIdx.x; i < min(n, base + TOHC_BP_CHUNK); i += TOHC_BP_THREADS) {
+        Aabb bx;
+        int x;
+        if (pass == 0) {
+          const float *t = dm.stat_soa + i;
+          const int P = dm.n_stat_pad;
+          bx.lo = mk(t[0], t[P], t[2 * P]);
+          bx.hi = mk(t[3 * P], t[4 * P], t[5 * P]);
+          if (!aabbOverlap(bq, bx)) continue;
+          x = dm.stat_children[i];
+        } else {
+          bx = ldAabb(dynAabb0 + ((size_t)set0 * dm.n_dyn_children + i) * 6);
+          if (!aabbOverlap(bq, bx)) continue;
+          x = dm.dyn_children[i];
+        }
+        const int X = sc.child_obj[x];
+        if (X == Q) continue;
+        const int gx = sc.obj_group[X];
+        if (cp.cast ? !(gx & TOHC_GROUP_KINBODY) : !(gx & (short)cp.filter_mask)) continue;  // cast: mask = KinBodyFilter (bcc:983)
+        if (!allowedRow[X]) continue;
+        s_hits[atomicAdd(&s_n, 1u)] = x;
+      }
+      __syncthreads();
+      const unsigned int nh = s_n;
+      if (nh > 0) {
+        if (threadIdx.x == 0) s_base = atomicAdd(&cnt->n_pairs[shard], nh);
+        __syncthreads();
+        const unsigned int b0 = s_base;
+        for (unsigned int k = threadIdx.x; k < nh; k += TOHC_BP_THREADS) {
+          const unsigned int pos = b0 + k;
+          if (pos < cp.seg_cap) {
+            PairRec p;
+            p.set = cs; p.q = q; p.x = s_hits[k]; p.pad = 0;
+            pairs[(size_t)shard * cp.seg_cap + pos] = p;
+          } else {
+            cnt->overflow = 1;
+          }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+      }
+    }
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// narrowphase
+// -----------------------------------------------------------------------------------------------------------------
+struct NarrowArgs {
+  DevScene sc;
+  DynMap dm;
+  DevRobot rb;
+  CallParams cp;
+  const float *dynXf0, *dynXf1;
+  const double *linkQT;   // [n_sets][n_links][7], null in poses mode
+  const double *dofs;     // [n_sets][K]
+  PairRec *pairs;
+  EpaRec *epaq;
+  HitRec *hits;
+  Counters *cnt;
+  unsigned int *n_records;   // records already in the slab (append) -- bumped by k_bump
+  tohc_record *records;
+  double *grads;             // [max_records][2][K]
+};
+
+struct PairIds {
+  int set0, set1, Q, qc, X, xc;
+  bool xIsA;  // X's child is GJK's A (X is a compound), else the query child is A (dispatch roles)
+};
+__device__ __forceinline__ void pairIds(const NarrowArgs &a, const PairRec &p, PairIds &c) {
+  castSets(a.cp, p.set, c.set0, c.set1);
+  c.Q = a.sc.child_obj[p.q]; c.X = a.sc.child_obj[p.x];
+  c.qc = a.sc.child_idx[p.q]; c.xc = a.sc.child_idx[p.x];
+  c.xIsA = a.sc.obj_compound[c.X] != 0;
+}
+template <int G>
+__device__ __forceinline__ void loadShape(const DevScene &sc, int child, Cvx<G> &c) {
+  const int sh = sc.child_shape[child];
+  cvxLoad<G>(c, sc.shape_kind[sh], mk(sc.shape_dims[3 * sh], sc.shape_dims[3 * sh + 1], sc.shape_dims[3 * sh + 2]), sc.vx, sc.vy, sc.vz,
+             sc.shape_voff[sh], sc.shape_vcnt[sh]);
+}
+__device__ __forceinline__ Xf childXf(const NarrowArgs &a, const float *dyn, int set, int child) {
+  const int s = a.dm.child_dyn[child];
+  return s >= 0 ? ldXf(dyn + ((size_t)set * a.dm.n_dyn_children + s) * 12) : ldXf(a.sc.stat_xf + 12 * child);
+}
+// operands of one pair with Bullet's A/B roles
+template <int G>
+__device__ __forceinline__ void loadPair(const NarrowArgs &a, const PairRec &p, const PairIds &c, Cvx<G> &A, Cvx<G> &B, Xf &tA, Xf &tB) {
+  Xf tq = childXf(a, a.dynXf0, c.set0, p.q);
+  Xf tx = childXf(a, a.dynXf0, c.set0, p.x);
+  Cvx<G> &cq = c.xIsA ? B : A;
+  Cvx<G> &cx = c.xIsA ? A : B;
+  loadShape<G>(a.sc, p.q, cq);
+  loadShape<G>(a.sc, p.x, cx);
+  if (a.cp.cast) {
+    Xf tq1 = childXf(a, a.dynXf1, c.set1, p.q);
+    cq.cast = 1;
+    cq.t01 = xfInverseTimes(tq, tq1);  // CastHullShape(convex, tf0.inverseTimes(tf1)), bullet_collision_checker.cpp:977
+  }
+  if (c.xIsA) { tA = tx; tB = tq; } else { tA = tq; tB = tx; }
+}
+
+// Bullet's output filter [gjk:430-449] + the collector's distance filter (bullet_collision_checker.cpp:401)
+template <int G>
+__device__ __forceinline__ void pushIfContact(const NarrowArgs &a, unsigned int pairPos, const GjkState &st, float md2) {
+  PairOut o;
+  gjkOutput(st, md2, o);
+  if (!o.valid) return;
+  if ((double)o.distance > (double)a.cp.d) return;
+  if (Grp<G>::lane() == 0) {
+    const int shard = blockIdx.x % TOHC_NSHARD;
+    unsigned int slot = atomicAdd(&a.cnt->n_hits[shard], 1u);
+    if (slot < a.cp.seg_cap) {
+      HitRec h;
+      h.pair = (int)pairPos;
+      h.distance = o.distance;
+      h.n[0] = o.normalOnB.x; h.n[1] = o.normalOnB.y; h.n[2] = o.normalOnB.z;
+      h.pB[0] = o.pointOnB.x; h.pB[1] = o.pointOnB.y; h.pB[2] = o.pointOnB.z;
+      a.hits[(size_t)shard * a.cp.seg_cap + slot] = h;
+    } else {
+      a.cnt->overflow = 1;
+    }
+  }
+}
+
+template <int G>
+__global__ void __launch_bounds__(256) k_gjk(NarrowArgs a) {
+  const int groupsPerBlock = 256 / G;
+  const unsigned int gid = blockIdx.x * groupsPerBlock + threadIdx.x / G;
+  const unsigned int ngroups = gridDim.x * groupsPerBlock;
+  QPrefix pre;
+  qprefix(a.cnt->n_pairs, a.cp.seg_cap, pre);
+  const unsigned int npairs = pre.start[TOHC_NSHARD];
+  float md2 = a.cp.breaking;
+  md2 *= md2;  // (marginA + marginB + gContactBreakingThreshold)^2 with zero margins [cca:370-373]
+  for (unsigned int p = gid; p < npairs; p += ngroups) {
+    const unsigned int pos = qlocate(pre, a.cp.seg_cap, p);
+    const PairRec pr = a.pairs[pos];
+    PairIds ids;
+    pairIds(a, pr, ids);
+    Cvx<G> A, B;
+    Xf tA, tB;
+    loadPair<G>(a, pr, ids, A, B, tA, tB);
+    GjkState st;
+    gjkMain<G>(A, B, tA, tB, md2, st);
+    if (st.needEpa) {
+      if (Grp<G>::lane() == 0) {
+        const int shard = blockIdx.x % TOHC_NSHARD;
+        unsigned int slot = atomicAdd(&a.cnt->n_epa[shard], 1u);
+        if (slot < a.cp.seg_cap) {
+          EpaRec e;
+          e.pair = (int)pos;
+          e.isValid = st.isValid;
+          e.distance = st.distance;
+          e.n[0] = st.normalInB.x; e.n[1] = st.normalInB.y; e.n[2] = st.normalInB.z;
+          e.pB[0] = st.pointOnB.x; e.pB[1] = st.pointOnB.y; e.pB[2] = st.pointOnB.z;
+          a.epaq[(size_t)shard * a.cp.seg_cap + slot] = e;
+        } else {
+          a.cnt->overflow = 1;
+        }
+      }
+    } else {
+      pushIfContact<G>(a, pos, st, md2);
+    }
+  }
+}
+
+template <int G, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_epa(NarrowArgs a) {
+  __shared__ EpaMem mem[BLOCK / G];
+  const int groupsPerBlock = BLOCK / G;
+  const unsigned int gid = blockIdx.x * groupsPerBlock + threadIdx.x / G;
+  const unsigned int ngroups = gridDim.x * groupsPerBlock;
+  QPrefix pre;
+  qprefix(a.cnt->n_epa, a.cp.seg_cap, pre);
+  const unsigned int nepa = pre.start[TOHC_NSHARD];
+  EpaMem *m = &mem[threadIdx.x / G];
+  float md2 = a.cp.breaking;
+  md2 *= md2;
+  for (unsigned int i = gid; i < nepa; i += ngroups) {
+    const EpaRec e = a.epaq[qlocate(pre, a.cp.seg_cap, i)];
+    const PairRec pr = a.pairs[e.pair];
+    PairIds ids;
+    pairIds(a, pr, ids);
+    Cvx<G> A, B;
+    Xf tA, tB;
+    loadPair<G>(a, pr, ids, A, B, tA, tB);
+    GjkState st;
+    st.isValid = e.isValid != 0;
+    st.needEpa = true;
+    st.distance = e.distance;
+    st.normalInB = mk(e.n[0], e.n[1], e.n[2]);
+    st.pointOnB = mk(e.pB[0], e.pB[1], e.pB[2]);
+    st.offset = (tA.o + tB.o) * 0.5f;
+    st.iters = 0;
+    gjkFinishEpa<G>(m, A, B, tA, tB, st);
+    pushIfContact<G>(a, (unsigned int)e.pair, st, md2);
+  }
+}
+
+// point Jacobian of `link` at world point p, column k: CalculateActiveJacobian as used by PositionJacobian
+// (configuration_space.cpp:83-89).  Chain walked leaf -> root like the oracle, so sums round identically.
+__device__ __forceinline__ D3 jacColumn(const DevRobot &rb, const double *linkQT, const double *q, int link, D3 p, int k) {
+  D3 J = mkd(0, 0, 0);
+  if (k < rb.n_joint_inds) {
+    for (int i = link; i >= 0; i = rb.parent[i]) {
+      if (rb.jtype[i] == TOHC_J_FIXED || rb.dof_col[i] != k) continue;
+      Dxf t = dxfFrom7(linkQT + 7 * i);
+      D3 z = qrot(t.q, mkd(rb.axis[3 * i], rb.axis[3 * i + 1], rb.axis[3 * i + 2]));
+      D3 col = rb.jtype[i] == TOHC_J_REVOLUTE ? cross(z, p - t.t) : z;
+      J.x += rb.mult[i] * col.x; J.y += rb.mult[i] * col.y; J.z += rb.mult[i] * col.z;
+    }
+    return J;
+  }
+  int kk = rb.n_joint_inds;
+  if (rb.affine & TOHC_DOF_X) { if (k == kk) return mkd(1, 0, 0); ++kk; }
+  if (rb.affine & TOHC_DOF_Y) { if (k == kk) return mkd(0, 1, 0); ++kk; }
+  if (rb.affine & TOHC_DOF_Z) { if (k == kk) return mkd(0, 0, 1); ++kk; }
+  if (rb.affine & TOHC_DOF_ROTAXIS) {
+    if (k == kk) {
+      const double *a = q + rb.n_joint_inds;
+      D3 bt = mkd(0, 0, 0);
+      if (rb.affine & TOHC_DOF_X) bt.x = *a++;
+      if (rb.affine & TOHC_DOF_Y) bt.y = *a++;
+      if (rb.affine & TOHC_DOF_Z) bt.z = *a++;
+      return cross(mkd(rb.rot_axis[0], rb.rot_axis[1], rb.rot_axis[2]), p - bt);
+    }
+  }
+  return J;
+}
+
+// CollisionsToDistanceExpressions for one contact at one configuration (collision_terms.cpp:44-56):
+// lanes of the group take the columns k = gl, gl+G, ...; the constant term is summed in column order.
+template <int G>
+__device__ __forceinline__ double linearizeAt(const NarrowArgs &a, int set, int la, int lb, D3 n, D3 ptA, D3 ptB, double dist, double *gradOut) {
+  const DevRobot &rb = a.rb;
+  const int gl = Grp<G>::lane();
+  const double *linkQT = a.linkQT + (size_t)set * rb.n_links * 7;
+  const double *q = a.dofs + (size_t)set * rb.K;
+  double gq = 0;
+  for (int k0 = 0; k0 < rb.K; k0 += G) {
+    const int k = k0 + gl;
+    double g = 0;
+    if (k < rb.K) {
+      if (la >= 0) {
+        D3 J = jacColumn(rb, linkQT, q, la, ptA, k);
+        g += 1.0 * (n.x * J.x + n.y * J.y + n.z * J.z);
+      }
+      if (lb >= 0) {
+        D3 J = jacColumn(rb, linkQT, q, lb, ptB, k);
+        g += -1.0 * (n.x * J.x + n.y * J.y + n.z * J.z);
+      }
+      gradOut[k] = g;
+    }
+    const int lim = min(G, rb.K - k0);
+    for (int j = 0; j < lim; ++j) {
+      double gj = __shfl(g, j, G);
+      gq += gj * q[k0 + j];
+    }
+  }
+  return dist - gq;
+}
+
+// k_finish: btBridgedManifoldResult::addContactPoint (btCollisionWorld.cpp:1068-1086), CastCollisionCollector
+// (bullet_collision_checker.cpp:894-972), record + gradient rows.
+template <int G>
+__global__ void __launch_bounds__(256) k_finish(NarrowArgs a) {
+  const int groupsPerBlock = 256 / G;
+  const unsigned int gid = blockIdx.x * groupsPerBlock + threadIdx.x / G;
+  const unsigned int ngroups = gridDim.x * groupsPerBlock;
+  QPrefix pre;
+  qprefix(a.cnt->n_hits, a.cp.seg_cap, pre);
+  const unsigned int nhits = pre.start[TOHC_NSHARD];
+  const unsigned int base = *a.n_records;
+  const int gl = Grp<G>::lane();
+  for (unsigned int hIdx = gid; hIdx < nhits; hIdx += ngroups) {
+    const unsigned int slot = base + hIdx;
+    if (slot >= a.cp.max_records) {
+      if (gl == 0) a.cnt->overflow = 1;
+      continue;
+    }
+    const HitRec h = a.hits[qlocate(pre, a.cp.seg_cap, hIdx)];
+    const PairRec pr = a.pairs[h.pair];
+    PairIds c;
+    pairIds(a, pr, c);
+    V3 nrm = mk(h.n[0], h.n[1], h.n[2]);
+    V3 ptB = mk(h.pB[0], h.pB[1], h.pB[2]);
+    V3 ptA = ptB + nrm * h.distance;
+    int idA = c.xIsA ? c.X : c.Q, chA = c.xIsA ? c.xc : c.qc;
+    int idB = c.xIsA ? c.Q : c.X, chB = c.xIsA ? c.qc : c.xc;
+    int cctype = TOHC_CC_NONE;
+    float time = 0;
+    V3 ptB1 = mk(0, 0, 0);
+    if (a.cp.cast) {
+      const bool castFirst = !c.xIsA;
+      Cvx<G> cq;
+      loadShape<G>(a.sc, pr.q, cq);
+      Xf tf0 = childXf(a, a.dynXf0, c.set0, pr.q);
+      Xf tq1 = childXf(a, a.dynXf1, c.set1, pr.q);
+      Xf t01 = xfInverseTimes(tf0, tq1);
+      Xf tw1 = xfMul(tf0, t01);  // m_cow->getWorldTransform() * shape->m_t01, bullet_collision_checker.cpp:904
+      CastOut co;
+      castClassify<G>(cq, tf0, tw1, nrm, ptA, ptB, castFirst, co);
+      if (castFirst) {  // swap so that the swept link is B (bullet_collision_checker.cpp:913-917)
+        V3 t = ptA; ptA = ptB; ptB = t;
+        nrm = nrm * -1.0f;
+        int ti = idA; idA = idB; idB = ti;
+        ti = chA; chA = chB; chB = ti;
+      }
+      cctype = co.cctype;
+      time = co.time;
+      if (co.between) { ptB = co.ptB; ptB1 = co.ptB1; }
+    }
+    double c0 = 0, c1 = 0;
+    if (a.cp.want_jac && a.linkQT) {
+      const int la = a.rb.obj_jaclink[idA], lb = a.rb.obj_jaclink[idB];
+      D3 n = mkd(nrm.x, nrm.y, nrm.z), pA = mkd(ptA.x, ptA.y, ptA.z), pB = mkd(ptB.x, ptB.y, ptB.z), pB1 = mkd(ptB1.x, ptB1.y, ptB1.z);
+      double *g = a.grads + (size_t)slot * 2 * a.rb.K;
+      c0 = linearizeAt<G>(a, c.set0, la, lb, n, pA, pB, (double)h.distance, g);
+      if (a.cp.cast) {
+        c1 = linearizeAt<G>(a, c.set1, la, lb, n, pA, (cctype == TOHC_CC_BETWEEN) ? pB1 : pB, (double)h.distance, g + a.rb.K);
+      } else {
+        for (int k = gl; k < a.rb.K; k += G) g[a.rb.K + k] = 0;
+      }
+    }
+    if (gl == 0) {
+      tohc_record r;
+      r.problem = c.set0 / a.cp.T;
+      r.t = c.set0 % a.cp.T;
+      r.idA = idA; r.childA = chA; r.idB = idB; r.childB = chB;
+      r.cctype = cctype;
+      r.time = time;
+      r.dist = h.distance;
+      r.n[0] = nrm.x; r.n[1] = nrm.y; r.n[2] = nrm.z;
+      r.ptA[0] = ptA.x; r.ptA[1] = ptA.y; r.ptA[2] = ptA.z;
+      r.ptB[0] = ptB.x; r.ptB[1] = ptB.y; r.ptB[2] = ptB.z;
+      r.ptB1[0] = ptB1.x; r.ptB1[1] = ptB1.y; r.ptB1[2] = ptB1.z;
+      r.const0 = c0; r.const1 = c1;
+      a.records[slot] = r;
+    }
+  }
+}
+
+// after k_finish: the slab now holds base + hits records
+__global__ void k_bump(Counters *cnt, unsigned int segCap, unsigned int *n_records) {
+  QPrefix pre;
+  qprefix(cnt->n_hits, segCap, pre);
+  *n_records += pre.start[TOHC_NSHARD];
+}
+
+}  // namespace tohc

@@ -30,15 +30,27 @@ struct Grp {
 #if defined(__HIPCC__)
   static TOHC_DEV int lane() { return (int)(threadIdx.x & (G - 1)); }
   static TOHC_DEV float bcast(float v, int src) { return __shfl(v, src, G); }
+  // lexicographic (max value, min index) all-reduce.  Inside a 16-lane DPP row the butterfly is four single VALU
+  // DPP moves (quad_perm xor-1, quad_perm xor-2, row_half_mirror, row_mirror): no LDS crossbar round trips.
+  static TOHC_DEV void combine(float &v, int &i, float ov, int oi) {
+    bool take = (ov > v) || (ov == v && oi < i);
+    v = take ? ov : v;
+    i = take ? oi : i;
+  }
+  template <int CTRL>
+  static TOHC_DEV void dppStep(float &v, int &i) {
+    int vi = __float_as_int(v);
+    float ov = __int_as_float(__builtin_amdgcn_update_dpp(vi, vi, CTRL, 0xf, 0xf, false));
+    int oi = __builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, false);
+    combine(v, i, ov, oi);
+  }
   static TOHC_DEV void argmax(float &v, int &i) {
+    dppStep<0xB1>(v, i);   // quad_perm [1,0,3,2]
+    dppStep<0x4E>(v, i);   // quad_perm [2,3,0,1]
+    dppStep<0x141>(v, i);  // row_half_mirror
+    dppStep<0x140>(v, i);  // row_mirror
 #pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) {
-      float ov = __shfl_xor(v, m, G);
-      int oi = __shfl_xor(i, m, G);
-      bool take = (ov > v) || (ov == v && oi < i);
-      v = take ? ov : v;
-      i = take ? oi : i;
-    }
+    for (int m = 16; m < G; m <<= 1) combine(v, i, __shfl_xor(v, m, G), __shfl_xor(i, m, G));
   }
   static TOHC_DEV float sum_ordered(float v, int n) {  // sum of lanes' v over vertex order is not needed; placeholder
     return v;
