@@ -377,7 +377,7 @@ __device__ __forceinline__ void pushIfContact(const NarrowArgs &a, unsigned int 
 }
 
 template <int G>
-__global__ void __launch_bounds__(256) k_gjk(NarrowArgs a) {
+__global__ void __launch_bounds__(256, 2) k_gjk(NarrowArgs a) {
   const int groupsPerBlock = 256 / G;
   const unsigned int gid = blockIdx.x * groupsPerBlock + threadIdx.x / G;
   const unsigned int ngroups = gridDim.x * groupsPerBlock;
