@@ -30,12 +30,16 @@ void load(const World *w, int child, Cvx<1> &c) {
   cvxLoad<1>(c, s.kind, s.dims, w->vx.data(), w->vy.data(), w->vz.data(), s.voff, s.n);
 }
 Xf childWorld(const World *w, int obj, int c, const Xf &T) { return w->compound[obj] ? xfMul(T, w->child_T[w->off[obj] + c]) : T; }
+long g_iter_hist[64];
+long g_epa_hist[2];
 bool pairEval(World *w, const Cvx<1> &A, const Xf &tA, const Cvx<1> &B, const Xf &tB, ora_contact *c) {
   float md = w->breaking;
   md *= md;
   GjkState st;
   w->pair_evals++;
   gjkMain<1>(A, B, tA, tB, md, st);
+  g_iter_hist[st.iters < 63 ? st.iters : 63]++;
+  g_epa_hist[st.needEpa ? 1 : 0]++;
   if (st.needEpa) {
     static EpaMem mem;
     w->epa_evals++;
@@ -181,5 +185,6 @@ int emu_cast_vs_all(void *h, const double *objT7, const int *q, int nq, const do
   }
   return n;
 }
+long emu_iter_hist(int i) { return g_iter_hist[i]; }
 long emu_counter(void *h, int which) { World *w = (World *)h; return which == 0 ? w->pair_evals : w->epa_evals; }
 }

@@ -72,6 +72,7 @@ struct tohc_engine {
   DBuf<int> d_shape_kind, d_shape_voff, d_shape_vcnt, d_child_shape, d_child_obj, d_child_idx, d_obj_off, d_obj_cnt, d_obj_compound, d_obj_group;
   DBuf<float> d_shape_dims, d_shape_lmin, d_shape_lmax, d_vx, d_vy, d_vz, d_child_localT, d_stat_xf, d_stat_aabb;
   DBuf<unsigned char> d_allowed;
+  DBuf<ChildDesc> d_child_desc;
   float d = 0.05f, breaking = 0;
 
   // robot
@@ -218,6 +219,20 @@ static int refreshStatic(tohc_engine *e) {
   }
   HIPCHK(upload(e->d_stat_xf, xf, e->stream));
   HIPCHK(upload(e->d_stat_aabb, bb, e->stream));
+  {
+    std::vector<ChildDesc> cd(e->n_children);
+    for (int c = 0; c < e->n_children; ++c) {
+      ChildDesc &d = cd[c];
+      memset(&d, 0, sizeof d);
+      const int sh = e->h_child_shape[c], obj = e->h_child_obj[c];
+      d.obj = obj; d.idx = e->h_child_idx[c]; d.kind = e->h_shape_kind[sh]; d.compound = e->h_obj_compound[obj];
+      d.voff = e->h_shape_voff[sh]; d.vcnt = e->h_shape_vcnt[sh];
+      d.dynR = e->h_child_dynR.empty() ? -1 : e->h_child_dynR[c];
+      for (int k = 0; k < 3; ++k) d.dims[k] = e->h_shape_dims[3 * sh + k];
+    }
+    HIPCHK(upload(e->d_child_desc, cd, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
   // SoA cull-box table of the children that never move in robot mode (everything until a robot is uploaded)
   const std::vector<int> &st = e->h_stat_childrenR;
   e->n_statR = (int)st.size();
@@ -443,7 +458,7 @@ static DevScene devScene(tohc_engine *e) {
   s.vx = e->d_vx.p; s.vy = e->d_vy.p; s.vz = e->d_vz.p;
   s.child_shape = e->d_child_shape.p; s.child_obj = e->d_child_obj.p; s.child_idx = e->d_child_idx.p; s.child_localT = e->d_child_localT.p;
   s.obj_off = e->d_obj_off.p; s.obj_cnt = e->d_obj_cnt.p; s.obj_compound = e->d_obj_compound.p; s.obj_group = e->d_obj_group.p;
-  s.allowed = e->d_allowed.p; s.stat_xf = e->d_stat_xf.p; s.stat_aabb = e->d_stat_aabb.p;
+  s.allowed = e->d_allowed.p; s.stat_xf = e->d_stat_xf.p; s.stat_aabb = e->d_stat_aabb.p; s.child_desc = e->d_child_desc.p;
   return s;
 }
 static DevRobot devRobot(tohc_engine *e) {
@@ -541,6 +556,7 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
   HIPCHK(hipMemsetAsync(e->d_cnt.p + slot, 0, sizeof(Counters), s));
   if (!append) HIPCHK(hipMemsetAsync(e->d_nrec.p, 0, sizeof(unsigned int), s));
   cp.seg_cap = (unsigned int)(e->max_pairs / TOHC_NSHARD); cp.max_records = (unsigned int)e->max_records;
+  cp.dbg_max_iter = getenv("TOHC_DBG_MAXITER") ? atoi(getenv("TOHC_DBG_MAXITER")) : 1000;
   const size_t qcap = (size_t)cp.seg_cap * TOHC_NSHARD;
   HIPCHK(e->d_pairs.reserve(qcap)); HIPCHK(e->d_epaq.reserve(qcap)); HIPCHK(e->d_hits.reserve(qcap));
   HIPCHK(e->d_records.reserve(e->max_records));
@@ -562,8 +578,13 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
     a.pairs = e->d_pairs.p; a.epaq = e->d_epaq.p; a.hits = e->d_hits.p; a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p;
     a.records = e->d_records.p; a.grads = e->d_grads.p;
     const int gridN = 256 * 8;
-    if (e->group == 64) hipLaunchKernelGGL((k_gjk<64>), dim3(gridN), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_gjk<16>), dim3(gridN), dim3(256), 0, s, a);
+    if (e->group == 64) {
+      if (cp.cast) hipLaunchKernelGGL((k_gjk<64, true>), dim3(gridN), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((k_gjk<64, false>), dim3(gridN), dim3(256), 0, s, a);
+    } else {
+      if (cp.cast) hipLaunchKernelGGL((k_gjk<16, true>), dim3(gridN), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((k_gjk<16, false>), dim3(gridN), dim3(256), 0, s, a);
+    }
     HIPCHK(hipEventRecord(ev[4], s));
     if (e->group == 64) hipLaunchKernelGGL((k_epa<64, 64>), dim3(gridN), dim3(64), 0, s, a);
     else hipLaunchKernelGGL((k_epa<16, 64>), dim3(gridN), dim3(64), 0, s, a);

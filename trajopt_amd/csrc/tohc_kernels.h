@@ -21,6 +21,14 @@ namespace tohc {
 
 #define TOHC_NSHARD 16
 
+struct ChildDesc {   // 48 B, one 16-B-aligned record per child: cuts the dependent-load chain of the pair set-up to
+  int obj, idx;      // pair -> desc -> vertices
+  int kind, compound;
+  int voff, vcnt;
+  int dynR, pad;     // slot among the robot's moving children (robot mode) or -1
+  float dims[3];
+  float pad2;
+};
 struct DevScene {
   int n_shapes, n_children, n_objects;
   const int *shape_kind, *shape_voff, *shape_vcnt;
@@ -30,6 +38,7 @@ struct DevScene {
   const float *child_localT;                          // [n][12] rows of the 3x3 then origin
   const int *obj_off, *obj_cnt, *obj_compound, *obj_group;
   const unsigned char *allowed;
+  const struct ChildDesc *child_desc;                 // [n_children] everything the narrowphase needs about a child, packed
   const float *stat_xf;                               // [n_children][12] world transform when the object is static
   const float *stat_aabb;                             // [n_children][6]
 };
@@ -68,6 +77,7 @@ struct CallParams {
   float d, breaking;
   unsigned int seg_cap;      // capacity of ONE shard of the pair / EPA / hit queues
   unsigned int max_records;
+  int dbg_max_iter;          // diagnostics only: 1000 = the reference's gGjkMaxIter
 };
 
 __host__ __device__ __forceinline__ Xf ldXf(const float *p) {
@@ -336,21 +346,16 @@ __device__ __forceinline__ Xf childXf(const NarrowArgs &a, const float *dyn, int
   const int s = a.dm.child_dyn[child];
   return s >= 0 ? ldXf(dyn + ((size_t)set * a.dm.n_dyn_children + s) * 12) : ldXf(a.sc.stat_xf + 12 * child);
 }
-// operands of one pair with Bullet's A/B roles
+// one side of a pair: shape into registers + its world pose(s)
 template <int G>
-__device__ __forceinline__ void loadPair(const NarrowArgs &a, const PairRec &p, const PairIds &c, Cvx<G> &A, Cvx<G> &B, Xf &tA, Xf &tB) {
-  Xf tq = childXf(a, a.dynXf0, c.set0, p.q);
-  Xf tx = childXf(a, a.dynXf0, c.set0, p.x);
-  Cvx<G> &cq = c.xIsA ? B : A;
-  Cvx<G> &cx = c.xIsA ? A : B;
-  loadShape<G>(a.sc, p.q, cq);
-  loadShape<G>(a.sc, p.x, cx);
-  if (a.cp.cast) {
-    Xf tq1 = childXf(a, a.dynXf1, c.set1, p.q);
-    cq.cast = 1;
-    cq.t01 = xfInverseTimes(tq, tq1);  // CastHullShape(convex, tf0.inverseTimes(tf1)), bullet_collision_checker.cpp:977
+__device__ __forceinline__ void loadSide(const NarrowArgs &a, int child, const ChildDesc &cd, int set0, int set1, bool cast, Cvx<G> &c, Xf &t0) {
+  cvxLoad<G>(c, cd.kind, mk(cd.dims[0], cd.dims[1], cd.dims[2]), a.sc.vx, a.sc.vy, a.sc.vz, cd.voff, cd.vcnt);
+  t0 = childXf(a, a.dynXf0, set0, child);
+  if (cast) {
+    Xf t1 = childXf(a, a.dynXf1, set1, child);
+    c.cast = 1;
+    c.t01 = xfInverseTimes(t0, t1);  // CastHullShape(convex, tf0.inverseTimes(tf1)), bullet_collision_checker.cpp:977
   }
-  if (c.xIsA) { tA = tx; tB = tq; } else { tA = tq; tB = tx; }
 }
 
 // Bullet's output filter [gjk:430-449] + the collector's distance filter (bullet_collision_checker.cpp:401)
@@ -376,7 +381,11 @@ __device__ __forceinline__ void pushIfContact(const NarrowArgs &a, unsigned int 
   }
 }
 
-template <int G>
+// Pairs are handed out in runs of TOHC_RUN consecutive list entries per group: the broadphase writes the survivors of
+// one (unit, query child) block contiguously, so within a run the query side (shape registers, pose, swept transform)
+// is usually unchanged and only the other side is reloaded.
+#define TOHC_RUN 8
+template <int G, bool CAST>
 __global__ void __launch_bounds__(256, 2) k_gjk(NarrowArgs a) {
   const int groupsPerBlock = 256 / G;
   const unsigned int gid = blockIdx.x * groupsPerBlock + threadIdx.x / G;
@@ -386,34 +395,51 @@ __global__ void __launch_bounds__(256, 2) k_gjk(NarrowArgs a) {
   const unsigned int npairs = pre.start[TOHC_NSHARD];
   float md2 = a.cp.breaking;
   md2 *= md2;  // (marginA + marginB + gContactBreakingThreshold)^2 with zero margins [cca:370-373]
-  for (unsigned int p = gid; p < npairs; p += ngroups) {
-    const unsigned int pos = qlocate(pre, a.cp.seg_cap, p);
-    const PairRec pr = a.pairs[pos];
-    PairIds ids;
-    pairIds(a, pr, ids);
-    Cvx<G> A, B;
-    Xf tA, tB;
-    loadPair<G>(a, pr, ids, A, B, tA, tB);
-    GjkState st;
-    gjkMain<G>(A, B, tA, tB, md2, st);
-    if (st.needEpa) {
-      if (Grp<G>::lane() == 0) {
-        const int shard = blockIdx.x % TOHC_NSHARD;
-        unsigned int slot = atomicAdd(&a.cnt->n_epa[shard], 1u);
-        if (slot < a.cp.seg_cap) {
-          EpaRec e;
-          e.pair = (int)pos;
-          e.isValid = st.isValid;
-          e.distance = st.distance;
-          e.n[0] = st.normalInB.x; e.n[1] = st.normalInB.y; e.n[2] = st.normalInB.z;
-          e.pB[0] = st.pointOnB.x; e.pB[1] = st.pointOnB.y; e.pB[2] = st.pointOnB.z;
-          a.epaq[(size_t)shard * a.cp.seg_cap + slot] = e;
-        } else {
-          a.cnt->overflow = 1;
-        }
+  Cvx<G> cq, cx;
+  Xf tq, tx;
+  int lastQ = -1, lastSet = -1;
+  for (unsigned int run = gid * TOHC_RUN; run < npairs; run += ngroups * TOHC_RUN) {
+    const unsigned int runEnd = min(run + TOHC_RUN, npairs);
+    for (unsigned int p = run; p < runEnd; ++p) {
+      const unsigned int pos = qlocate(pre, a.cp.seg_cap, p);
+      const PairRec pr = a.pairs[pos];
+      const ChildDesc dx = a.sc.child_desc[pr.x];
+      if (pr.q != lastQ || pr.set != lastSet) {
+        const ChildDesc dq = a.sc.child_desc[pr.q];
+        int set0, set1;
+        castSets(a.cp, pr.set, set0, set1);
+        loadSide<G>(a, pr.q, dq, set0, set1, CAST, cq, tq);
+        lastQ = pr.q; lastSet = pr.set;
       }
-    } else {
-      pushIfContact<G>(a, pos, st, md2);
+      {
+        int set0, set1;
+        castSets(a.cp, pr.set, set0, set1);
+        loadSide<G>(a, pr.x, dx, set0, set1, false, cx, tx);
+      }
+      // GJK roles: X compound -> A = X child, B = query child; else A = query child, B = X
+      GjkState st;
+      const bool xIsA = dx.compound != 0;
+      if (xIsA) gjkMain<G>(cx, cq, tx, tq, md2, st, a.cp.dbg_max_iter);
+      else gjkMain<G>(cq, cx, tq, tx, md2, st, a.cp.dbg_max_iter);
+      if (st.needEpa) {
+        if (Grp<G>::lane() == 0) {
+          const int shard = blockIdx.x % TOHC_NSHARD;
+          unsigned int slot = atomicAdd(&a.cnt->n_epa[shard], 1u);
+          if (slot < a.cp.seg_cap) {
+            EpaRec e;
+            e.pair = (int)pos;
+            e.isValid = st.isValid;
+            e.distance = st.distance;
+            e.n[0] = st.normalInB.x; e.n[1] = st.normalInB.y; e.n[2] = st.normalInB.z;
+            e.pB[0] = st.pointOnB.x; e.pB[1] = st.pointOnB.y; e.pB[2] = st.pointOnB.z;
+            a.epaq[(size_t)shard * a.cp.seg_cap + slot] = e;
+          } else {
+            a.cnt->overflow = 1;
+          }
+        }
+      } else {
+        pushIfContact<G>(a, pos, st, md2);
+      }
     }
   }
 }
@@ -433,11 +459,18 @@ __global__ void __launch_bounds__(BLOCK) k_epa(NarrowArgs a) {
   for (unsigned int i = gid; i < nepa; i += ngroups) {
     const EpaRec e = a.epaq[qlocate(pre, a.cp.seg_cap, i)];
     const PairRec pr = a.pairs[e.pair];
-    PairIds ids;
-    pairIds(a, pr, ids);
+    const ChildDesc dq = a.sc.child_desc[pr.q], dx = a.sc.child_desc[pr.x];
+    int set0, set1;
+    castSets(a.cp, pr.set, set0, set1);
     Cvx<G> A, B;
     Xf tA, tB;
-    loadPair<G>(a, pr, ids, A, B, tA, tB);
+    if (dx.compound) {
+      loadSide<G>(a, pr.x, dx, set0, set1, false, A, tA);
+      loadSide<G>(a, pr.q, dq, set0, set1, a.cp.cast != 0, B, tB);
+    } else {
+      loadSide<G>(a, pr.q, dq, set0, set1, a.cp.cast != 0, A, tA);
+      loadSide<G>(a, pr.x, dx, set0, set1, false, B, tB);
+    }
     GjkState st;
     st.isValid = e.isValid != 0;
     st.needEpa = true;

@@ -410,7 +410,7 @@ struct GjkState {
 };
 
 template <int G>
-TOHC_DEV void gjkMain(const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &tB, float maxDist2, GjkState &st) {
+TOHC_DEV void gjkMain(const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &tB, float maxDist2, GjkState &st, int maxIter = 1000) {
   float distance = 0;
   V3 normalInB = mk(0, 0, 0), pointOnB = mk(0, 0, 0);
   Xf lA = tA, lB = tB;
@@ -418,7 +418,6 @@ TOHC_DEV void gjkMain(const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &
   lA.o = lA.o - offset;
   lB.o = lB.o - offset;
   int curIter = 0;
-  const int maxIter = 1000;
   V3 sep = mk(0, 1, 0);
   bool isValid = false, checkSimplex = false;
   int degenerate = 0;
