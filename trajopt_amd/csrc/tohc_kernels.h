@@ -395,32 +395,48 @@ __global__ void __launch_bounds__(256, 2) k_gjk(NarrowArgs a) {
   const unsigned int npairs = pre.start[TOHC_NSHARD];
   float md2 = a.cp.breaking;
   md2 *= md2;  // (marginA + marginB + gContactBreakingThreshold)^2 with zero margins [cca:370-373]
-  Cvx<G> cq, cx;
-  Xf tq, tx;
+  const int maxIter = a.cp.dbg_max_iter;
+  // operands live in their GJK roles; the query child stays in its role register across pairs when it can
+  Cvx<G> cA, cB;
+  Xf tA, tB;
+  GjkRun<G> g;
   int lastQ = -1, lastSet = -1;
-  for (unsigned int run = gid * TOHC_RUN; run < npairs; run += ngroups * TOHC_RUN) {
-    const unsigned int runEnd = min(run + TOHC_RUN, npairs);
-    for (unsigned int p = run; p < runEnd; ++p) {
-      const unsigned int pos = qlocate(pre, a.cp.seg_cap, p);
+  bool qInB = false;
+  bool active = false;
+  unsigned int run = gid * TOHC_RUN, p = run, runEnd = min(run + TOHC_RUN, npairs);
+  unsigned int pos = 0;
+  for (;;) {
+    if (!active) {
+      if (p >= runEnd) {  // this group's run is used up (or was empty): take the next one
+        run += ngroups * TOHC_RUN;
+        if (run >= npairs) break;
+        p = run;
+        runEnd = min(run + TOHC_RUN, npairs);
+      }
+      pos = qlocate(pre, a.cp.seg_cap, p);
+      ++p;
       const PairRec pr = a.pairs[pos];
       const ChildDesc dx = a.sc.child_desc[pr.x];
-      if (pr.q != lastQ || pr.set != lastSet) {
-        const ChildDesc dq = a.sc.child_desc[pr.q];
-        int set0, set1;
-        castSets(a.cp, pr.set, set0, set1);
-        loadSide<G>(a, pr.q, dq, set0, set1, CAST, cq, tq);
-        lastQ = pr.q; lastSet = pr.set;
-      }
-      {
-        int set0, set1;
-        castSets(a.cp, pr.set, set0, set1);
-        loadSide<G>(a, pr.x, dx, set0, set1, false, cx, tx);
-      }
+      int set0, set1;
+      castSets(a.cp, pr.set, set0, set1);
       // GJK roles: X compound -> A = X child, B = query child; else A = query child, B = X
-      GjkState st;
       const bool xIsA = dx.compound != 0;
-      if (xIsA) gjkMain<G>(cx, cq, tx, tq, md2, st, a.cp.dbg_max_iter);
-      else gjkMain<G>(cq, cx, tq, tx, md2, st, a.cp.dbg_max_iter);
+      const bool needQ = !(pr.q == lastQ && pr.set == lastSet && qInB == xIsA);
+      if (xIsA) {
+        loadSide<G>(a, pr.x, dx, set0, set1, false, cA, tA);
+        if (needQ) loadSide<G>(a, pr.q, a.sc.child_desc[pr.q], set0, set1, CAST, cB, tB);
+      } else {
+        loadSide<G>(a, pr.x, dx, set0, set1, false, cB, tB);
+        if (needQ) loadSide<G>(a, pr.q, a.sc.child_desc[pr.q], set0, set1, CAST, cA, tA);
+      }
+      lastQ = pr.q; lastSet = pr.set; qInB = xIsA;
+      g.init(tA, tB);
+      active = true;
+    }
+    if (g.step(cA, cB, tA, tB, md2, maxIter)) {
+      GjkState st;
+      g.finish(st);
+      active = false;
       if (st.needEpa) {
         if (Grp<G>::lane() == 0) {
           const int shard = blockIdx.x % TOHC_NSHARD;

@@ -158,17 +158,17 @@ struct Simplex {
   SubRes bc;
 };
 
+// value selects, not conditional stores: a store through a phi of addresses keeps the whole simplex in scratch memory
+TOHC_DEV V3 sel3(bool c, V3 a, V3 b) { return mk(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
 TOHC_DEV V3 pick(const V3 *a, int i) {
   V3 r = a[0];
 #pragma unroll
-  for (int k = 1; k < 4; ++k)
-    if (k == i) r = a[k];
+  for (int k = 1; k < 4; ++k) r = sel3(k == i, a[k], r);
   return r;
 }
 TOHC_DEV void put(V3 *a, int i, V3 v) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (k == i) a[k] = v;
+  for (int k = 0; k < 4; ++k) a[k] = sel3(k == i, v, a[k]);
 }
 TOHC_DEV void subResReset(SubRes &r) {
   r.degenerate = false;
@@ -183,8 +183,10 @@ TOHC_DEV void vssReset(Simplex &s) {
   s.needsUpdate = true;
   s.lastW = mk(1e18f, 1e18f, 1e18f);
   subResReset(s.bc);
-  for (int k = 0; k < 4; ++k) s.W[k] = s.P[k] = s.Q[k] = mk(0, 0, 0);
+#if !defined(__HIPCC__)
+  for (int k = 0; k < 4; ++k) s.W[k] = s.P[k] = s.Q[k] = mk(0, 0, 0);  // host build: keep sanitizers quiet
   s.cP1 = s.cP2 = s.cV = mk(0, 0, 0);
+#endif
 }
 template <int I>
 TOHC_DEV void vssRemove(Simplex &s) {
@@ -409,68 +411,91 @@ struct GjkState {
   int iters;
 };
 
+// The loop of getClosestPointsNonVirtual as a resumable object: init(), step() until it returns true, finish().
+// k_gjk keeps one of these per group and refills a group with its next pair as soon as its loop ends, so the groups
+// of a wavefront never wait for the slowest pair (iteration counts range from 1 to ~8, two thirds end after two).
 template <int G>
-TOHC_DEV void gjkMain(const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &tB, float maxDist2, GjkState &st, int maxIter = 1000) {
-  float distance = 0;
-  V3 normalInB = mk(0, 0, 0), pointOnB = mk(0, 0, 0);
-  Xf lA = tA, lB = tB;
-  V3 offset = (lA.o + lB.o) * 0.5f;
-  lA.o = lA.o - offset;
-  lB.o = lB.o - offset;
-  int curIter = 0;
-  V3 sep = mk(0, 1, 0);
-  bool isValid = false, checkSimplex = false;
-  int degenerate = 0;
-  float squaredDistance = 1e18f, delta = 0;
+struct GjkRun {
   Simplex sx;
-  vssReset(sx);
-  for (;;) {
+  V3 sep, offset, oA, oB;
+  float squaredDistance;
+  int curIter, degenerate;
+  bool checkSimplex;
+
+  TOHC_DEV void init(const Xf &tA, const Xf &tB) {
+    offset = (tA.o + tB.o) * 0.5f;
+    oA = tA.o - offset;
+    oB = tB.o - offset;
+    curIter = 0;
+    sep = mk(0, 1, 0);
+    checkSimplex = false;
+    degenerate = 0;
+    squaredDistance = 1e18f;
+    vssReset(sx);
+  }
+  // one pass of the for(;;) body [gjk:137-302]; true = the loop has ended
+  TOHC_DEV bool step(const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &tB, float maxDist2, int maxIter) {
     V3 sepA = mulVM(-sep, tA.b);
     V3 sepB = mulVM(sep, tB.b);
     V3 pInA = supNV<G>(A, sepA);
     V3 qInB = supNV<G>(B, sepB);
-    V3 pW = xfApply(lA, pInA);
-    V3 qW = xfApply(lB, qInB);
+    V3 pW = mulMV(tA.b, pInA) + oA;
+    V3 qW = mulMV(tB.b, qInB) + oB;
     V3 w = pW - qW;
-    delta = dot(sep, w);
-    if ((delta > 0.0f) && (delta * delta > squaredDistance * maxDist2)) { degenerate = 10; checkSimplex = true; break; }
-    if (vssInSimplex(sx, w)) { degenerate = 1; checkSimplex = true; break; }
+    float delta = dot(sep, w);
+    if ((delta > 0.0f) && (delta * delta > squaredDistance * maxDist2)) { degenerate = 10; checkSimplex = true; return true; }
+    if (vssInSimplex(sx, w)) { degenerate = 1; checkSimplex = true; return true; }
     float f0 = squaredDistance - delta;
     float f1 = squaredDistance * 1.0e-6f;
-    if (f0 <= f1) { degenerate = (f0 <= 0.0f) ? 2 : 11; checkSimplex = true; break; }
+    if (f0 <= f1) { degenerate = (f0 <= 0.0f) ? 2 : 11; checkSimplex = true; return true; }
     vssAdd(sx, w, pW, qW);
     bool ok = vssUpdate(sx);
     V3 newSep = sx.cV;
-    if (!ok) { degenerate = 3; checkSimplex = true; break; }
-    if (len2(newSep) < 1.0e-6f) { sep = newSep; degenerate = 6; checkSimplex = true; break; }
+    if (!ok) { degenerate = 3; checkSimplex = true; return true; }
+    if (len2(newSep) < 1.0e-6f) { sep = newSep; degenerate = 6; checkSimplex = true; return true; }
     float prev = squaredDistance;
     squaredDistance = len2(newSep);
-    if (prev - squaredDistance <= FLT_EPSILON * prev) { checkSimplex = true; degenerate = 12; break; }
+    if (prev - squaredDistance <= FLT_EPSILON * prev) { checkSimplex = true; degenerate = 12; return true; }
     sep = newSep;
-    if (curIter++ > maxIter) break;
-    if (sx.n == 4) { degenerate = 13; break; }
+    if (curIter++ > maxIter) return true;
+    if (sx.n == 4) { degenerate = 13; return true; }
+    return false;
   }
-  if (checkSimplex) {
-    vssUpdate(sx);
-    pointOnB = sx.cP2;
-    normalInB = sep;
-    float lenSqr = len2(sep);
-    if ((double)lenSqr < 0.0001) degenerate = 5;
-    if (lenSqr > FLT_EPSILON * FLT_EPSILON) {
-      float rlen = 1.0f / sqrtf(lenSqr);
-      normalInB = normalInB * rlen;
-      distance = (1.0f / rlen);
-      isValid = true;
+  // [gjk:304-335]
+  TOHC_DEV void finish(GjkState &st) {
+    float distance = 0;
+    V3 normalInB = mk(0, 0, 0), pointOnB = mk(0, 0, 0);
+    bool isValid = false;
+    if (checkSimplex) {
+      vssUpdate(sx);
+      pointOnB = sx.cP2;
+      normalInB = sep;
+      float lenSqr = len2(sep);
+      if ((double)lenSqr < 0.0001) degenerate = 5;
+      if (lenSqr > FLT_EPSILON * FLT_EPSILON) {
+        float rlen = 1.0f / sqrtf(lenSqr);
+        normalInB = normalInB * rlen;
+        distance = (1.0f / rlen);
+        isValid = true;
+      }
     }
+    bool catchDeg = degenerate && ((double)distance < 0.01);
+    st.isValid = isValid;
+    st.needEpa = (!isValid || catchDeg);
+    st.distance = distance;
+    st.normalInB = normalInB;
+    st.pointOnB = pointOnB;
+    st.offset = offset;
+    st.iters = curIter;
   }
-  bool catchDeg = degenerate && ((double)distance < 0.01);
-  st.isValid = isValid;
-  st.needEpa = (!isValid || catchDeg);
-  st.distance = distance;
-  st.normalInB = normalInB;
-  st.pointOnB = pointOnB;
-  st.offset = offset;
-  st.iters = curIter;
+};
+
+template <int G>
+TOHC_DEV void gjkMain(const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &tB, float maxDist2, GjkState &st, int maxIter = 1000) {
+  GjkRun<G> r;
+  r.init(tA, tB);
+  while (!r.step(A, B, tA, tB, maxDist2, maxIter)) {}
+  r.finish(st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
