@@ -182,7 +182,7 @@ def main():
 
     if rank == 0:
         launches = c1["cum_launches"] - c0["cum_launches"]
-        ms = {k: (c1["cum_ms_" + k] - c0["cum_ms_" + k]) / max(launches, 1) for k in ("fk", "children", "broadphase", "gjk", "epa")}
+        ms = {k: (c1["cum_ms_" + k] - c0["cum_ms_" + k]) / max(launches, 1) for k in ("fk", "children", "broadphase", "gjk", "epa", "finish")}
         # roofline of the dominant kernel (k_gjk): algorithmic bytes per pair-eval (SURVEY.md 8d / DESIGN.md):
         #   12*(nA+nB) vertices + 96 two fp32 3x4 transforms + [152 + 16*K if a record is written]
         a = s.arrays

@@ -63,13 +63,17 @@ typedef struct tohc_record {
 typedef struct tohc_counters {
   /* since the last sync (all enqueues it covered) */
   int64_t aabb_tests;   /* (timestep, query child, other child) tuples examined by the broadphase    */
-  int64_t pair_evals;   /* tuples that survived the cull and got a GJK evaluation                     */
+  int64_t pair_evals;   /* tuples that survived the box cull: signed-distance pair evaluations         */
   int64_t epa_evals;    /* of those, how many went through GJK2+EPA                                   */
   int64_t contacts;     /* records in the slab                                                        */
   double ms_last_call;  /* device time of those enqueues (HIP events on the engine's stream)          */
   /* cumulative since tohc_create; per-kernel device time from HIP events around every launch         */
   int64_t cum_aabb_tests, cum_pair_evals, cum_epa_evals, cum_launches;
   double cum_ms_fk, cum_ms_children, cum_ms_broadphase, cum_ms_gjk, cum_ms_epa;
+  /* pair evaluations the separating-axis pre-test inside the broadphase kernel could not finish ("farther than d")
+   * and that therefore ran the iterative GJK; gjk_evals <= pair_evals */
+  int64_t gjk_evals, cum_gjk_evals;
+  double cum_ms_finish; /* k_finish (cast classification, records, gradient rows); cum_ms_epa is k_epa alone */
 } tohc_counters;
 
 /* replaces CreateCollisionChecker(env)                       src/trajopt/bullet_collision_checker.cpp:1036-1039 */

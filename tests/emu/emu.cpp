@@ -32,11 +32,22 @@ void load(const World *w, int child, Cvx<1> &c) {
 Xf childWorld(const World *w, int obj, int c, const Xf &T) { return w->compound[obj] ? xfMul(T, w->child_T[w->off[obj] + c]) : T; }
 long g_iter_hist[64];
 long g_epa_hist[2];
+long g_pre[8];
 bool pairEval(World *w, const Cvx<1> &A, const Xf &tA, const Cvx<1> &B, const Xf &tB, ora_contact *c) {
   float md = w->breaking;
   md *= md;
   GjkState st;
   w->pair_evals++;
+  int pre = 0;
+  {
+    float lim = w->d * 1.01f + 1e-4f;
+    V3 ww;
+    V3 dir = tA.o - tB.o;
+    if (len2(dir) > 1e-12f && sepAxisBeyond<1>(A, B, tA, tB, dir, lim, ww)) pre = 1;
+    else if (len2(ww) > 1e-12f && sepAxisBeyond<1>(A, B, tA, tB, ww, lim, ww)) pre = 2;
+    else if (len2(ww) > 1e-12f && sepAxisBeyond<1>(A, B, tA, tB, ww, lim, ww)) pre = 3;
+  }
+  g_pre[pre]++;
   gjkMain<1>(A, B, tA, tB, md, st);
   g_iter_hist[st.iters < 63 ? st.iters : 63]++;
   g_epa_hist[st.needEpa ? 1 : 0]++;
@@ -49,6 +60,7 @@ bool pairEval(World *w, const Cvx<1> &A, const Xf &tA, const Cvx<1> &B, const Xf
   gjkOutput(st, md, o);
   if (!o.valid) return false;
   if ((double)o.distance > (double)w->d) return false;
+  if (pre) g_pre[4 + pre]++;
   V3 pA = o.pointOnB + o.normalOnB * o.distance;
   c->dist = o.distance;
   c->n[0] = o.normalOnB.x; c->n[1] = o.normalOnB.y; c->n[2] = o.normalOnB.z;
@@ -185,6 +197,7 @@ int emu_cast_vs_all(void *h, const double *objT7, const int *q, int nq, const do
   }
   return n;
 }
+long emu_pre(int i) { return g_pre[i]; }
 long emu_iter_hist(int i) { return g_iter_hist[i]; }
 long emu_counter(void *h, int which) { World *w = (World *)h; return which == 0 ? w->pair_evals : w->epa_evals; }
 }

@@ -109,16 +109,18 @@ struct tohc_engine {
   // enqueue ring: every enqueue since the last sync has its own device counter slot and event set
   struct Pending { int slot; int64_t aabb_tests; };
   std::vector<Pending> pending;
-  std::vector<hipEvent_t> events;   // RING * 6
+  std::vector<hipEvent_t> events;   // RING * NEV
   DBuf<unsigned int> d_nrec;        // shared record counter
   HBuf<unsigned int> h_nrec;
   int staged_B = 0, staged_T = 0;
   bool staged = false;
   bool last_robot_mode = true, last_want_jac = false;
   size_t fetched_n = 0;
+  int pretest = 1;   // TOHC_PRETEST=0 turns the separating-axis pre-test off (A/B measurements)
   tohc_engine() { memset(&counters, 0, sizeof counters); }
 };
 static const int RING = 32;
+static const int NEV = 7;   // events per enqueue: fk | children | broadphase | gjk | epa | finish
 
 static int fail(tohc_engine *e, int code, const char *fmt, ...) {
   char buf[512];
@@ -168,8 +170,9 @@ int tohc_create(tohc_engine **out, int device) {
   }
   const char *g = getenv("TOHC_GROUP");
   if (g && atoi(g) == 64) e->group = 64;
+  if (const char *pt = getenv("TOHC_PRETEST")) e->pretest = atoi(pt) != 0;
   e->breaking = (float)(2.001 * (double)e->d);
-  e->events.resize((size_t)RING * 6);
+  e->events.resize((size_t)RING * NEV);
   for (auto &ev : e->events)
     if (hipEventCreate(&ev) != hipSuccess) { delete e; return TOHC_E_HIP; }
   if (e->d_cnt.reserve(RING) != hipSuccess || e->h_cnt.reserve(RING) != hipSuccess || e->d_nrec.reserve(1) != hipSuccess ||
@@ -500,25 +503,26 @@ static int syncEngine(tohc_engine *e) {
   bool overflow = false;
   unsigned int worst_pairs = 0;
   tohc_counters &c = e->counters;
-  c.aabb_tests = c.pair_evals = c.epa_evals = 0;
+  c.aabb_tests = c.pair_evals = c.epa_evals = c.gjk_evals = 0;
   c.ms_last_call = 0;
   for (const auto &pd : e->pending) {
     const Counters &k = e->h_cnt.p[pd.slot];
     const unsigned int segCap = (unsigned int)(e->max_pairs / TOHC_NSHARD);
-    unsigned int np = 0, ne = 0;
+    unsigned int np = 0, ne = 0, ng = 0;
     overflow |= k.overflow != 0;
     for (int sh = 0; sh < TOHC_NSHARD; ++sh) {
       overflow |= k.n_pairs[sh] > segCap || k.n_epa[sh] > segCap || k.n_hits[sh] > segCap;
-      np += k.n_pairs[sh]; ne += k.n_epa[sh];
+      np += k.n_cand[sh]; ng += k.n_pairs[sh]; ne += k.n_epa[sh];
     }
-    worst_pairs = std::max(worst_pairs, np);
-    c.aabb_tests += pd.aabb_tests; c.pair_evals += np; c.epa_evals += ne;
-    c.cum_aabb_tests += pd.aabb_tests; c.cum_pair_evals += np; c.cum_epa_evals += ne;
-    float ms[5] = {0, 0, 0, 0, 0};
-    hipEvent_t *ev = &e->events[(size_t)pd.slot * 6];
-    for (int i = 0; i < 5; ++i) HIPCHK(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+    worst_pairs = std::max(worst_pairs, ng);
+    c.aabb_tests += pd.aabb_tests; c.pair_evals += np; c.epa_evals += ne; c.gjk_evals += ng;
+    c.cum_aabb_tests += pd.aabb_tests; c.cum_pair_evals += np; c.cum_epa_evals += ne; c.cum_gjk_evals += ng;
+    float ms[NEV - 1] = {0, 0, 0, 0, 0, 0};
+    hipEvent_t *ev = &e->events[(size_t)pd.slot * NEV];
+    for (int i = 0; i < NEV - 1; ++i) HIPCHK(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
     c.cum_ms_fk += ms[0]; c.cum_ms_children += ms[1]; c.cum_ms_broadphase += ms[2]; c.cum_ms_gjk += ms[3]; c.cum_ms_epa += ms[4];
-    c.ms_last_call += ms[0] + ms[1] + ms[2] + ms[3] + ms[4];
+    c.cum_ms_finish += ms[5];
+    c.ms_last_call += ms[0] + ms[1] + ms[2] + ms[3] + ms[4] + ms[5];
     c.cum_launches += 1;
   }
   e->pending.clear();
@@ -552,7 +556,7 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
   const int nQ = (int)h_qchildren.size();
   const int K = robotMode ? e->K : 1;
   hipStream_t s = e->stream;
-  hipEvent_t *ev = &e->events[(size_t)slot * 6];
+  hipEvent_t *ev = &e->events[(size_t)slot * NEV];
   HIPCHK(hipMemsetAsync(e->d_cnt.p + slot, 0, sizeof(Counters), s));
   if (!append) HIPCHK(hipMemsetAsync(e->d_nrec.p, 0, sizeof(unsigned int), s));
   cp.seg_cap = (unsigned int)(e->max_pairs / TOHC_NSHARD); cp.max_records = (unsigned int)e->max_records;
@@ -567,9 +571,6 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
     const size_t blocks = (size_t)cp.n_cast_sets * nQ;
     if (blocks > 0x7fffffffull) return fail(e, TOHC_E_CAPACITY, "broadphase grid too large (%zu blocks)", blocks);
     const bool sep1 = cp.gap == 0 && cp.cast;  // poses mode keeps the end-of-sweep poses in their own tables
-    hipLaunchKernelGGL(k_broadphase, dim3((unsigned)blocks), dim3(TOHC_BP_THREADS), 0, s, sc, dm, cp, d_qchildren, nQ, e->d_dynAabb.p,
-                       sep1 ? e->d_dynAabb1.p : e->d_dynAabb.p, e->d_pairs.p, e->d_cnt.p + slot);
-    HIPCHK(hipEventRecord(ev[3], s));
     NarrowArgs a;
     a.sc = sc; a.dm = dm; a.rb = devRobot(e); a.cp = cp;
     a.dynXf0 = e->d_dynXf.p; a.dynXf1 = sep1 ? e->d_dynXf1.p : e->d_dynXf.p;
@@ -577,6 +578,13 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
     a.dofs = robotMode ? e->d_dofs.p : nullptr;
     a.pairs = e->d_pairs.p; a.epaq = e->d_epaq.p; a.hits = e->d_hits.p; a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p;
     a.records = e->d_records.p; a.grads = e->d_grads.p;
+    CullArgs ca;
+    ca.a = a; ca.qchildren = d_qchildren; ca.nQ = nQ;
+    ca.dynAabb0 = e->d_dynAabb.p; ca.dynAabb1 = sep1 ? e->d_dynAabb1.p : e->d_dynAabb.p;
+    ca.pretest = e->pretest;
+    if (cp.cast) hipLaunchKernelGGL((k_broadphase<true>), dim3((unsigned)blocks), dim3(TOHC_BP_THREADS), 0, s, ca);
+    else hipLaunchKernelGGL((k_broadphase<false>), dim3((unsigned)blocks), dim3(TOHC_BP_THREADS), 0, s, ca);
+    HIPCHK(hipEventRecord(ev[3], s));
     const int gridN = 256 * 8;
     if (e->group == 64) {
       if (cp.cast) hipLaunchKernelGGL((k_gjk<64, true>), dim3(gridN), dim3(256), 0, s, a);
@@ -588,13 +596,14 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
     HIPCHK(hipEventRecord(ev[4], s));
     if (e->group == 64) hipLaunchKernelGGL((k_epa<64, 64>), dim3(gridN), dim3(64), 0, s, a);
     else hipLaunchKernelGGL((k_epa<16, 64>), dim3(gridN), dim3(64), 0, s, a);
+    HIPCHK(hipEventRecord(ev[5], s));
     if (e->group == 64) hipLaunchKernelGGL((k_finish<64>), dim3(256 * 2), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_finish<16>), dim3(256 * 2), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, s, e->d_cnt.p + slot, cp.seg_cap, e->d_nrec.p);
-    HIPCHK(hipEventRecord(ev[5], s));
+    HIPCHK(hipEventRecord(ev[6], s));
     HIPCHK(hipGetLastError());
   } else {
-    HIPCHK(hipEventRecord(ev[3], s)); HIPCHK(hipEventRecord(ev[4], s)); HIPCHK(hipEventRecord(ev[5], s));
+    for (int i = 3; i < NEV; ++i) HIPCHK(hipEventRecord(ev[i], s));
   }
   tohc_engine::Pending pd;
   pd.slot = slot;
@@ -641,7 +650,7 @@ static int enqueueRobot(tohc_engine *e, int gap, int cast, int filter_mask, int 
   const int B = e->staged_B, T = e->staged_T;
   const size_t n_sets = (size_t)B * T;
   hipStream_t s = e->stream;
-  hipEvent_t *ev = &e->events[(size_t)slot * 6];
+  hipEvent_t *ev = &e->events[(size_t)slot * NEV];
   HIPCHK(hipEventRecord(ev[0], s));
   DynMap dm = dynMapRobot(e);
   hipLaunchKernelGGL(k_fk, dim3((unsigned)n_sets), dim3(64), (size_t)e->n_links * 7 * sizeof(double), s, devRobot(e), devScene(e), dm, e->d_dofs.p,
@@ -751,7 +760,7 @@ static int posesQuery(tohc_engine *e, const double *obj_T, const double *cast_T1
   if (rc != TOHC_OK) return rc;
   e->staged = false;  // the pose tables below overwrite the staged robot tables
   hipStream_t s = e->stream;
-  hipEvent_t *ev = &e->events[(size_t)slot * 6];
+  hipEvent_t *ev = &e->events[(size_t)slot * NEV];
   HIPCHK(hipEventRecord(ev[0], s));
   HIPCHK(hipEventRecord(ev[1], s));
   const size_t nobj = e->n_objects, nch = e->n_children;

@@ -65,6 +65,7 @@ struct EpaRec { int pair; int isValid; float distance; float n[3]; float pB[3]; 
 struct HitRec { int pair; float distance; float n[3]; float pB[3]; };
 struct Counters {  // one per enqueue
   unsigned int n_pairs[TOHC_NSHARD], n_epa[TOHC_NSHARD], n_hits[TOHC_NSHARD];
+  unsigned int n_cand[TOHC_NSHARD];  // box-test survivors = pair evaluations; n_pairs = those the pre-test passes on to k_gjk
   unsigned int overflow, pad[15];
 };
 
@@ -231,82 +232,6 @@ __global__ void k_dyn_children(DevScene sc, DynMap dm, const double *__restrict_
 }
 
 // -----------------------------------------------------------------------------------------------------------------
-// k_broadphase: filters follow CollisionCollector::needsCollision (bullet_collision_checker.cpp:409-413) and
-// btSingleContactCallback::process (btCollisionWorld.cpp:1129-1137); the cull is the engine's own conservative box
-// test (same arithmetic as oracle/trajopt_oracle.c shapeAabb): both boxes grown by d, closed-interval overlap -- it
-// can never drop a pair whose distance is <= d.
-// -----------------------------------------------------------------------------------------------------------------
-#define TOHC_BP_THREADS 256
-#define TOHC_BP_CHUNK 2048
-__global__ void __launch_bounds__(TOHC_BP_THREADS) k_broadphase(DevScene sc, DynMap dm, CallParams cp, const int *__restrict__ qchildren, int nQ,
-                                                                const float *__restrict__ dynAabb0, const float *__restrict__ dynAabb1,
-                                                                PairRec *__restrict__ pairs, Counters *__restrict__ cnt) {
-  __shared__ int s_hits[TOHC_BP_CHUNK];
-  __shared__ unsigned int s_n, s_base;
-  const int qi = blockIdx.x % nQ;
-  const int cs = blockIdx.x / nQ;
-  const int q = qchildren[qi];
-  const int Q = sc.child_obj[q];
-  const int shard = blockIdx.x % TOHC_NSHARD;
-  int set0, set1;
-  castSets(cp, cs, set0, set1);
-  const int qs = dm.child_dyn[q];
-  Aabb bq = qs >= 0 ? ldAabb(dynAabb0 + ((size_t)set0 * dm.n_dyn_children + qs) * 6) : ldAabb(sc.stat_aabb + 6 * q);
-  if (cp.cast && qs >= 0) bq = aabbUnion(bq, ldAabb(dynAabb1 + ((size_t)set1 * dm.n_dyn_children + qs) * 6));
-  const unsigned char *allowedRow = sc.allowed + (size_t)Q * sc.n_objects;
-  if (threadIdx.x == 0) s_n = 0;
-  __syncthreads();
-  // two passes: children that never move (SoA table, coalesced), then the moving ones (robot links / everything)
-  for (int pass = 0; pass < 2; ++pass) {
-    const int n = pass == 0 ? dm.n_stat : dm.n_dyn_children;
-    for (int base = 0; base < n; base += TOHC_BP_CHUNK) {
-      for (int i = base + threadIdx.x; i < min(n, base + TOHC_BP_CHUNK); i += TOHC_BP_THREADS) {
-        Aabb bx;
-        int x;
-        if (pass == 0) {
-          const float *t = dm.stat_soa + i;
-          const int P = dm.n_stat_pad;
-          bx.lo = mk(t[0], t[P], t[2 * P]);
-          bx.hi = mk(t[3 * P], t[4 * P], t[5 * P]);
-          if (!aabbOverlap(bq, bx)) continue;
-          x = dm.stat_children[i];
-        } else {
-          bx = ldAabb(dynAabb0 + ((size_t)set0 * dm.n_dyn_children + i) * 6);
-          if (!aabbOverlap(bq, bx)) continue;
-          x = dm.dyn_children[i];
-        }
-        const int X = sc.child_obj[x];
-        if (X == Q) continue;
-        const int gx = sc.obj_group[X];
-        if (cp.cast ? !(gx & TOHC_GROUP_KINBODY) : !(gx & (short)cp.filter_mask)) continue;  // cast: mask = KinBodyFilter (bcc:983)
-        if (!allowedRow[X]) continue;
-        s_hits[atomicAdd(&s_n, 1u)] = x;
-      }
-      __syncthreads();
-      const unsigned int nh = s_n;
-      if (nh > 0) {
-        if (threadIdx.x == 0) s_base = atomicAdd(&cnt->n_pairs[shard], nh);
-        __syncthreads();
-        const unsigned int b0 = s_base;
-        for (unsigned int k = threadIdx.x; k < nh; k += TOHC_BP_THREADS) {
-          const unsigned int pos = b0 + k;
-          if (pos < cp.seg_cap) {
-            PairRec p;
-            p.set = cs; p.q = q; p.x = s_hits[k]; p.pad = 0;
-            pairs[(size_t)shard * cp.seg_cap + pos] = p;
-          } else {
-            cnt->overflow = 1;
-          }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) s_n = 0;
-        __syncthreads();
-      }
-    }
-  }
-}
-
-// -----------------------------------------------------------------------------------------------------------------
 // narrowphase
 // -----------------------------------------------------------------------------------------------------------------
 struct NarrowArgs {
@@ -355,6 +280,126 @@ __device__ __forceinline__ void loadSide(const NarrowArgs &a, int child, const C
     Xf t1 = childXf(a, a.dynXf1, set1, child);
     c.cast = 1;
     c.t01 = xfInverseTimes(t0, t1);  // CastHullShape(convex, tf0.inverseTimes(tf1)), bullet_collision_checker.cpp:977
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// k_broadphase: filters follow CollisionCollector::needsCollision (bullet_collision_checker.cpp:409-413) and
+// btSingleContactCallback::process (btCollisionWorld.cpp:1129-1137); the cull is the engine's own conservative box
+// test (same arithmetic as oracle/trajopt_oracle.c shapeAabb): both boxes grown by d, closed-interval overlap -- it
+// can never drop a pair whose distance is <= d.  Every box-test survivor is one PAIR EVALUATION (n_cand, what
+// tohc_counters.pair_evals reports, equal to the oracle's count).  The evaluation starts right here, while the query
+// child's shape sits in the block's registers: one support query along the line between the two origins bounds the
+// distance from below (sepAxisBeyond); pairs provably farther apart than d are finished, the rest go to k_gjk.
+// -----------------------------------------------------------------------------------------------------------------
+#define TOHC_BP_THREADS 256
+#define TOHC_BP_CHUNK 2048
+#define TOHC_BP_G 16
+struct CullArgs {
+  NarrowArgs a;
+  const int *qchildren;
+  int nQ;
+  const float *dynAabb0, *dynAabb1;
+  int pretest;
+};
+template <bool CAST>
+__global__ void __launch_bounds__(TOHC_BP_THREADS) k_broadphase(CullArgs ca) {
+  constexpr int G = TOHC_BP_G;
+  const NarrowArgs &a = ca.a;
+  const DevScene &sc = a.sc;
+  const DynMap &dm = a.dm;
+  const CallParams &cp = a.cp;
+  __shared__ int s_hits[TOHC_BP_CHUNK];
+  __shared__ int s_surv[TOHC_BP_CHUNK];
+  __shared__ unsigned int s_n, s_m, s_base;
+  const int qi = blockIdx.x % ca.nQ;
+  const int cs = blockIdx.x / ca.nQ;
+  const int q = ca.qchildren[qi];
+  const int Q = sc.child_obj[q];
+  const int shard = blockIdx.x % TOHC_NSHARD;
+  int set0, set1;
+  castSets(cp, cs, set0, set1);
+  const int qs = dm.child_dyn[q];
+  Aabb bq = qs >= 0 ? ldAabb(ca.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + qs) * 6) : ldAabb(sc.stat_aabb + 6 * q);
+  if (CAST && qs >= 0) bq = aabbUnion(bq, ldAabb(ca.dynAabb1 + ((size_t)set1 * dm.n_dyn_children + qs) * 6));
+  const unsigned char *allowedRow = sc.allowed + (size_t)Q * sc.n_objects;
+  if (threadIdx.x == 0) { s_n = 0; s_m = 0; }
+  __syncthreads();
+  const float lim = cp.d * 1.01f + 1.0e-4f;  // guard band: the bound and Bullet's result both carry ~1e-6 of rounding
+  bool haveQ = false;
+  Cvx<G> cq;
+  Xf tq;
+  // two passes: children that never move (SoA table, coalesced), then the moving ones (robot links / everything)
+  for (int pass = 0; pass < 2; ++pass) {
+    const int n = pass == 0 ? dm.n_stat : dm.n_dyn_children;
+    for (int base = 0; base < n; base += TOHC_BP_CHUNK) {
+      for (int i = base + threadIdx.x; i < min(n, base + TOHC_BP_CHUNK); i += TOHC_BP_THREADS) {
+        Aabb bx;
+        int x;
+        if (pass == 0) {
+          const float *t = dm.stat_soa + i;
+          const int P = dm.n_stat_pad;
+          bx.lo = mk(t[0], t[P], t[2 * P]);
+          bx.hi = mk(t[3 * P], t[4 * P], t[5 * P]);
+          if (!aabbOverlap(bq, bx)) continue;
+          x = dm.stat_children[i];
+        } else {
+          bx = ldAabb(ca.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + i) * 6);
+          if (!aabbOverlap(bq, bx)) continue;
+          x = dm.dyn_children[i];
+        }
+        const int X = sc.child_obj[x];
+        if (X == Q) continue;
+        const int gx = sc.obj_group[X];
+        if (CAST ? !(gx & TOHC_GROUP_KINBODY) : !(gx & (short)cp.filter_mask)) continue;  // cast: mask = KinBodyFilter (bcc:983)
+        if (!allowedRow[X]) continue;
+        s_hits[atomicAdd(&s_n, 1u)] = x;
+      }
+      __syncthreads();
+      const unsigned int nh = s_n;
+      if (nh > 0) {  // block-uniform
+        const int *out = s_hits;
+        unsigned int nout = nh;
+        if (ca.pretest) {
+          if (!haveQ) {
+            loadSide<G>(a, q, sc.child_desc[q], set0, set1, CAST, cq, tq);
+            haveQ = true;
+          }
+          for (unsigned int k = threadIdx.x / G; k < nh; k += TOHC_BP_THREADS / G) {
+            const int x = s_hits[k];
+            Cvx<G> cx;
+            Xf tx;
+            loadSide<G>(a, x, sc.child_desc[x], set0, set1, false, cx, tx);
+            const V3 dir = tq.o - tx.o;
+            V3 w;
+            const bool far = (len2(dir) > 1.0e-12f) && sepAxisBeyond<G>(cq, cx, tq, tx, dir, lim, w);
+            if (!far && Grp<G>::lane() == 0) s_surv[atomicAdd(&s_m, 1u)] = x;
+          }
+          __syncthreads();
+          out = s_surv;
+          nout = s_m;
+        }
+        if (threadIdx.x == 0) {
+          atomicAdd(&a.cnt->n_cand[shard], nh);
+          if (nout > 0) s_base = atomicAdd(&a.cnt->n_pairs[shard], nout);
+        }
+        __syncthreads();
+        const unsigned int b0 = s_base;
+        for (unsigned int k = threadIdx.x; k < nout; k += TOHC_BP_THREADS) {
+          const unsigned int pos = b0 + k;
+          if (pos < cp.seg_cap) {
+            PairRec p;
+            p.set = cs; p.q = q; p.x = out[k]; p.pad = 0;
+            a.pairs[(size_t)shard * cp.seg_cap + pos] = p;
+          } else {
+            a.cnt->overflow = 1;
+          }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { s_n = 0; s_m = 0; }
+        __syncthreads();
+      }
+    }
   }
 }
 

@@ -490,6 +490,20 @@ struct GjkRun {
   }
 };
 
+// Conservative separating-axis pre-test (no counterpart in the reference; it only removes pairs the reference would
+// evaluate and then drop): along ANY world direction `dir` the support points pA (of A, towards -dir) and qB (of B,
+// towards +dir) bound the distance from below by dot(dir, pA - qB) / |dir|.  When that bound exceeds `lim` (the
+// contact distance plus a guard band far above fp32 rounding of these few operations) no contact with distance <= d
+// exists, so the collector's filter (bullet_collision_checker.cpp:401) would discard whatever GJK returns.
+template <int G>
+TOHC_DEV bool sepAxisBeyond(const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &tB, V3 dir, float lim, V3 &w) {
+  V3 pA = xfApply(tA, supNV<G>(A, mulVM(-dir, tA.b)));
+  V3 qB = xfApply(tB, supNV<G>(B, mulVM(dir, tB.b)));
+  w = pA - qB;
+  float delta = dot(dir, w);
+  return (delta > 0.0f) && (delta * delta > (lim * lim) * len2(dir));
+}
+
 template <int G>
 TOHC_DEV void gjkMain(const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &tB, float maxDist2, GjkState &st, int maxIter = 1000) {
   GjkRun<G> r;

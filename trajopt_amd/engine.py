@@ -23,7 +23,8 @@ class Counters(C.Structure):
                 ("contacts", C.c_int64), ("ms_last_call", C.c_double),
                 ("cum_aabb_tests", C.c_int64), ("cum_pair_evals", C.c_int64), ("cum_epa_evals", C.c_int64),
                 ("cum_launches", C.c_int64), ("cum_ms_fk", C.c_double), ("cum_ms_children", C.c_double),
-                ("cum_ms_broadphase", C.c_double), ("cum_ms_gjk", C.c_double), ("cum_ms_epa", C.c_double)]
+                ("cum_ms_broadphase", C.c_double), ("cum_ms_gjk", C.c_double), ("cum_ms_epa", C.c_double),
+                ("gjk_evals", C.c_int64), ("cum_gjk_evals", C.c_int64), ("cum_ms_finish", C.c_double)]
 
 
 class EngineError(RuntimeError):
