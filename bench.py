@@ -212,6 +212,8 @@ def main():
                                    "discrete+cast collision costs with gradient rows; %d independent multi-start problems per GPU" % P,
                        "problems_per_gpu": P, "timesteps": T, "K": rb.K, "parallelism": "problems sharded over %d GPU(s), no collective" % world},
             "pair_evals_per_step_per_gpu": pair_evals / args.steps,
+            "gjk_evals_per_step_per_gpu": (c1["cum_gjk_evals"] - c0["cum_gjk_evals"]) / args.steps,
+            "epa_evals_per_step_per_gpu": (c1["cum_epa_evals"] - c0["cum_epa_evals"]) / args.steps,
             "contacts_per_step_per_gpu": int(c1["contacts"]),
             "ms_per_sqp_linearization_single_problem_host_delivered": lat_ms,
             "ms_per_sqp_linearization_single_problem_device": lat_dev_ms,

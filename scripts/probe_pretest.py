@@ -19,7 +19,7 @@ we.set_allowed(allowed)
 rng = np.random.default_rng(1000)
 traj = synth.fullbody_trajectory(rb, rng, 100)
 n = 0
-for t in range(0, 99, 9):
+for t in range(0, 99, 1):
     P = static_T.copy(); f0 = B.oracle_fk(rb, traj[t]); f1 = B.oracle_fk(rb, traj[t+1]); P[link_obj[have]] = f0[have]
     n += len(we.links_vs_all(P, objs))
     n += len(we.cast_vs_all(P, objs, f0[links], f1[links]))
@@ -27,4 +27,4 @@ lib = we.lib
 lib.emu_pre.restype = C.c_long; lib.emu_iter_hist.restype = C.c_long
 pre = [lib.emu_pre(i) for i in range(8)]
 print("contacts", n, "pairs", sum(pre[:4]), "pass/axis1/axis2/axis3", pre[:4], "violations", pre[5:8])
-print("iters", [lib.emu_iter_hist(i) for i in range(12)])
+print("iters", [lib.emu_iter_hist(i) for i in range(64)])

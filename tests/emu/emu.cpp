@@ -13,6 +13,7 @@ struct Shape { int kind; V3 dims, lmin, lmax; int voff, n; };
 struct World {
   std::vector<Shape> shapes;
   std::vector<float> vx, vy, vz;
+  std::vector<F4> v4;
   std::vector<int> child_shape;
   std::vector<Xf> child_T;
   std::vector<int> off, cnt, compound, group;
@@ -27,7 +28,7 @@ float safeMargin(float cur, float x, float y, float z) {
 }
 void load(const World *w, int child, Cvx<1> &c) {
   const Shape &s = w->shapes[w->child_shape[child]];
-  cvxLoad<1>(c, s.kind, s.dims, w->vx.data(), w->vy.data(), w->vz.data(), s.voff, s.n);
+  cvxLoad<1>(c, s.kind, s.dims, w->vx.data(), w->vy.data(), w->vz.data(), w->v4.data(), s.voff, s.n);
 }
 Xf childWorld(const World *w, int obj, int c, const Xf &T) { return w->compound[obj] ? xfMul(T, w->child_T[w->off[obj] + c]) : T; }
 long g_iter_hist[64];
@@ -95,6 +96,7 @@ void *emu_create(const ora_scene *sc) {
     w->shapes.push_back(s);
   }
   for (int i = 0; i < sc->n_verts; ++i) { w->vx.push_back(sc->verts[3 * i]); w->vy.push_back(sc->verts[3 * i + 1]); w->vz.push_back(sc->verts[3 * i + 2]); }
+  for (size_t i = 0; i < w->vx.size(); ++i) { F4 p; p.x = w->vx[i]; p.y = w->vy[i]; p.z = w->vz[i]; p.w = 0; w->v4.push_back(p); }
   w->vx.resize(w->vx.size() + 64); w->vy.resize(w->vy.size() + 64); w->vz.resize(w->vz.size() + 64);
   for (int i = 0; i < sc->n_children; ++i) { w->child_shape.push_back(sc->child_shape[i]); w->child_T.push_back(xfFrom7(sc->child_T + 7 * i)); }
   for (int i = 0; i < sc->n_objects; ++i) {

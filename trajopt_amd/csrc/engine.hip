@@ -71,6 +71,7 @@ struct tohc_engine {
   std::vector<unsigned char> h_allowed;
   DBuf<int> d_shape_kind, d_shape_voff, d_shape_vcnt, d_child_shape, d_child_obj, d_child_idx, d_obj_off, d_obj_cnt, d_obj_compound, d_obj_group;
   DBuf<float> d_shape_dims, d_shape_lmin, d_shape_lmax, d_vx, d_vy, d_vz, d_child_localT, d_stat_xf, d_stat_aabb;
+  DBuf<F4> d_v4;
   DBuf<unsigned char> d_allowed;
   DBuf<ChildDesc> d_child_desc;
   float d = 0.05f, breaking = 0;
@@ -116,6 +117,7 @@ struct tohc_engine {
   bool staged = false;
   bool last_robot_mode = true, last_want_jac = false;
   size_t fetched_n = 0;
+  int gjk_group = 1;  // lanes per pair in k_gjk: 1 (default), 16 or 64 (TOHC_GJK_GROUP)
   int pretest = 1;   // TOHC_PRETEST=0 turns the separating-axis pre-test off (A/B measurements)
   tohc_engine() { memset(&counters, 0, sizeof counters); }
 };
@@ -171,6 +173,8 @@ int tohc_create(tohc_engine **out, int device) {
   const char *g = getenv("TOHC_GROUP");
   if (g && atoi(g) == 64) e->group = 64;
   if (const char *pt = getenv("TOHC_PRETEST")) e->pretest = atoi(pt) != 0;
+  e->gjk_group = e->group == 64 ? 64 : 1;
+  if (const char *gg = getenv("TOHC_GJK_GROUP")) { int v = atoi(gg); if (v == 1 || v == 16 || v == 64) e->gjk_group = v; }
   e->breaking = (float)(2.001 * (double)e->d);
   e->events.resize((size_t)RING * NEV);
   for (auto &ev : e->events)
@@ -193,6 +197,7 @@ void tohc_destroy(tohc_engine *e) {
   DBuf<float> *fb[] = {&e->d_shape_dims, &e->d_shape_lmin, &e->d_shape_lmax, &e->d_vx, &e->d_vy, &e->d_vz, &e->d_child_localT, &e->d_stat_xf,
                        &e->d_stat_aabb, &e->d_dynXf, &e->d_dynAabb, &e->d_dynXf1, &e->d_dynAabb1};
   for (auto b : fb) b->release();
+  e->d_v4.release();
   DBuf<double> *db[] = {&e->d_T_origin, &e->d_axis, &e->d_mult, &e->d_offs, &e->d_q_robot, &e->d_dofs, &e->d_linkQT, &e->d_objQT, &e->d_objQT1, &e->d_grads};
   for (auto b : db) b->release();
   e->d_allowed.release(); e->d_pairs.release(); e->d_epaq.release(); e->d_cnt.release(); e->d_records.release();
@@ -324,6 +329,9 @@ int tohc_upload_scene(tohc_engine *e, int n_shapes, const int32_t *shape_kind, c
     std::vector<float> px((size_t)n_verts + 64, 0.f), py((size_t)n_verts + 64, 0.f), pz((size_t)n_verts + 64, 0.f);
     for (int i = 0; i < n_verts; ++i) { px[i] = vx[i]; py[i] = vy[i]; pz[i] = vz[i]; }
     HIPCHK(upload(e->d_vx, px, s)); HIPCHK(upload(e->d_vy, py, s)); HIPCHK(upload(e->d_vz, pz, s));
+    std::vector<F4> p4((size_t)n_verts + 64);
+    for (size_t i = 0; i < p4.size(); ++i) { p4[i].x = px[i]; p4[i].y = py[i]; p4[i].z = pz[i]; p4[i].w = 0.f; }
+    HIPCHK(upload(e->d_v4, p4, s));
     HIPCHK(hipStreamSynchronize(s));
   }
   HIPCHK(upload(e->d_child_shape, e->h_child_shape, s)); HIPCHK(upload(e->d_child_obj, e->h_child_obj, s)); HIPCHK(upload(e->d_child_idx, e->h_child_idx, s));
@@ -458,7 +466,7 @@ static DevScene devScene(tohc_engine *e) {
   s.n_shapes = e->n_shapes; s.n_children = e->n_children; s.n_objects = e->n_objects;
   s.shape_kind = e->d_shape_kind.p; s.shape_voff = e->d_shape_voff.p; s.shape_vcnt = e->d_shape_vcnt.p;
   s.shape_dims = e->d_shape_dims.p; s.shape_lmin = e->d_shape_lmin.p; s.shape_lmax = e->d_shape_lmax.p;
-  s.vx = e->d_vx.p; s.vy = e->d_vy.p; s.vz = e->d_vz.p;
+  s.vx = e->d_vx.p; s.vy = e->d_vy.p; s.vz = e->d_vz.p; s.v4 = e->d_v4.p;
   s.child_shape = e->d_child_shape.p; s.child_obj = e->d_child_obj.p; s.child_idx = e->d_child_idx.p; s.child_localT = e->d_child_localT.p;
   s.obj_off = e->d_obj_off.p; s.obj_cnt = e->d_obj_cnt.p; s.obj_compound = e->d_obj_compound.p; s.obj_group = e->d_obj_group.p;
   s.allowed = e->d_allowed.p; s.stat_xf = e->d_stat_xf.p; s.stat_aabb = e->d_stat_aabb.p; s.child_desc = e->d_child_desc.p;
@@ -586,12 +594,15 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
     else hipLaunchKernelGGL((k_broadphase<false>), dim3((unsigned)blocks), dim3(TOHC_BP_THREADS), 0, s, ca);
     HIPCHK(hipEventRecord(ev[3], s));
     const int gridN = 256 * 8;
-    if (e->group == 64) {
-      if (cp.cast) hipLaunchKernelGGL((k_gjk<64, true>), dim3(gridN), dim3(256), 0, s, a);
-      else hipLaunchKernelGGL((k_gjk<64, false>), dim3(gridN), dim3(256), 0, s, a);
+    if (e->gjk_group == 1) {  // one lane per pair, one wavefront per block
+      if (cp.cast) hipLaunchKernelGGL((k_gjk<1, true, 64>), dim3(gridN * 2), dim3(64), 0, s, a);
+      else hipLaunchKernelGGL((k_gjk<1, false, 64>), dim3(gridN * 2), dim3(64), 0, s, a);
+    } else if (e->gjk_group == 64) {
+      if (cp.cast) hipLaunchKernelGGL((k_gjk<64, true, 256>), dim3(gridN), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((k_gjk<64, false, 256>), dim3(gridN), dim3(256), 0, s, a);
     } else {
-      if (cp.cast) hipLaunchKernelGGL((k_gjk<16, true>), dim3(gridN), dim3(256), 0, s, a);
-      else hipLaunchKernelGGL((k_gjk<16, false>), dim3(gridN), dim3(256), 0, s, a);
+      if (cp.cast) hipLaunchKernelGGL((k_gjk<16, true, 256>), dim3(gridN), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((k_gjk<16, false, 256>), dim3(gridN), dim3(256), 0, s, a);
     }
     HIPCHK(hipEventRecord(ev[4], s));
     if (e->group == 64) hipLaunchKernelGGL((k_epa<64, 64>), dim3(gridN), dim3(64), 0, s, a);

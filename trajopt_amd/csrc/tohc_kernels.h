@@ -34,6 +34,7 @@ struct DevScene {
   const int *shape_kind, *shape_voff, *shape_vcnt;
   const float *shape_dims, *shape_lmin, *shape_lmax;  // [n][3]
   const float *vx, *vy, *vz;
+  const F4 *v4;                                       // the same vertices as 16-byte records (lane-per-pair GJK)
   const int *child_shape, *child_obj, *child_idx;
   const float *child_localT;                          // [n][12] rows of the 3x3 then origin
   const int *obj_off, *obj_cnt, *obj_compound, *obj_group;
@@ -264,7 +265,7 @@ __device__ __forceinline__ void pairIds(const NarrowArgs &a, const PairRec &p, P
 template <int G>
 __device__ __forceinline__ void loadShape(const DevScene &sc, int child, Cvx<G> &c) {
   const int sh = sc.child_shape[child];
-  cvxLoad<G>(c, sc.shape_kind[sh], mk(sc.shape_dims[3 * sh], sc.shape_dims[3 * sh + 1], sc.shape_dims[3 * sh + 2]), sc.vx, sc.vy, sc.vz,
+  cvxLoad<G>(c, sc.shape_kind[sh], mk(sc.shape_dims[3 * sh], sc.shape_dims[3 * sh + 1], sc.shape_dims[3 * sh + 2]), sc.vx, sc.vy, sc.vz, sc.v4,
              sc.shape_voff[sh], sc.shape_vcnt[sh]);
 }
 __device__ __forceinline__ Xf childXf(const NarrowArgs &a, const float *dyn, int set, int child) {
@@ -274,7 +275,7 @@ __device__ __forceinline__ Xf childXf(const NarrowArgs &a, const float *dyn, int
 // one side of a pair: shape into registers + its world pose(s)
 template <int G>
 __device__ __forceinline__ void loadSide(const NarrowArgs &a, int child, const ChildDesc &cd, int set0, int set1, bool cast, Cvx<G> &c, Xf &t0) {
-  cvxLoad<G>(c, cd.kind, mk(cd.dims[0], cd.dims[1], cd.dims[2]), a.sc.vx, a.sc.vy, a.sc.vz, cd.voff, cd.vcnt);
+  cvxLoad<G>(c, cd.kind, mk(cd.dims[0], cd.dims[1], cd.dims[2]), a.sc.vx, a.sc.vy, a.sc.vz, a.sc.v4, cd.voff, cd.vcnt);
   t0 = childXf(a, a.dynXf0, set0, child);
   if (cast) {
     Xf t1 = childXf(a, a.dynXf1, set1, child);
@@ -430,9 +431,9 @@ __device__ __forceinline__ void pushIfContact(const NarrowArgs &a, unsigned int 
 // one (unit, query child) block contiguously, so within a run the query side (shape registers, pose, swept transform)
 // is usually unchanged and only the other side is reloaded.
 #define TOHC_RUN 8
-template <int G, bool CAST>
-__global__ void __launch_bounds__(256, 2) k_gjk(NarrowArgs a) {
-  const int groupsPerBlock = 256 / G;
+template <int G, bool CAST, int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 2) k_gjk(NarrowArgs a) {
+  const int groupsPerBlock = BLOCK / G;
   const unsigned int gid = blockIdx.x * groupsPerBlock + threadIdx.x / G;
   const unsigned int ngroups = gridDim.x * groupsPerBlock;
   QPrefix pre;
@@ -448,15 +449,17 @@ __global__ void __launch_bounds__(256, 2) k_gjk(NarrowArgs a) {
   int lastQ = -1, lastSet = -1;
   bool qInB = false;
   bool active = false;
-  unsigned int run = gid * TOHC_RUN, p = run, runEnd = min(run + TOHC_RUN, npairs);
+  // short lists (after the pre-test they usually are): shorter runs, so that every group of the grid has work
+  const unsigned int runLen = min((unsigned int)TOHC_RUN, max(1u, (npairs + ngroups - 1) / ngroups));
+  unsigned int run = gid * runLen, p = run, runEnd = min(run + runLen, npairs);
   unsigned int pos = 0;
   for (;;) {
     if (!active) {
       if (p >= runEnd) {  // this group's run is used up (or was empty): take the next one
-        run += ngroups * TOHC_RUN;
+        run += ngroups * runLen;
         if (run >= npairs) break;
         p = run;
-        runEnd = min(run + TOHC_RUN, npairs);
+        runEnd = min(run + runLen, npairs);
       }
       pos = qlocate(pre, a.cp.seg_cap, p);
       ++p;
@@ -506,7 +509,7 @@ __global__ void __launch_bounds__(256, 2) k_gjk(NarrowArgs a) {
 }
 
 template <int G, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) k_epa(NarrowArgs a) {
+__global__ void __launch_bounds__(BLOCK, 2) k_epa(NarrowArgs a) {
   __shared__ EpaMem mem[BLOCK / G];
   const int groupsPerBlock = BLOCK / G;
   const unsigned int gid = blockIdx.x * groupsPerBlock + threadIdx.x / G;

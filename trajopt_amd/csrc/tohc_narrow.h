@@ -62,6 +62,15 @@ struct Grp {
 #endif
 };
 
+#if defined(__HIPCC__)
+template <>
+struct Grp<1> {  // one lane per pair: nothing to exchange
+  static TOHC_DEV int lane() { return 0; }
+  static TOHC_DEV float bcast(float v, int) { return v; }
+  static TOHC_DEV void argmax(float &, int &) {}
+};
+#endif
+
 enum { KIND_BOX = 0, KIND_HULL = 1 };
 
 template <int G>
@@ -73,8 +82,17 @@ struct Cvx {
   Xf t01;   // cast: T_0_1 = T_w_0^-1 * T_w_1
 };
 
+// G = 1: the hull stays in memory (64 pairs per wavefront leave no registers for vertices); a support query is a scan
+template <>
+struct Cvx<1> {
+  int kind, cast, n;
+  V3 dims;
+  const F4 *v;
+  Xf t01;
+};
+
 template <int G>
-TOHC_DEV void cvxLoad(Cvx<G> &c, int kind, V3 dims, const float *vx, const float *vy, const float *vz, int voff, int n) {
+TOHC_DEV void cvxLoad(Cvx<G> &c, int kind, V3 dims, const float *vx, const float *vy, const float *vz, const F4 *, int voff, int n) {
   c.kind = kind;
   c.cast = 0;
   c.n = n;
@@ -88,6 +106,15 @@ TOHC_DEV void cvxLoad(Cvx<G> &c, int kind, V3 dims, const float *vx, const float
     c.y[s] = in ? vy[voff + i] : 0.0f;
     c.z[s] = in ? vz[voff + i] : 0.0f;
   }
+}
+
+template <>
+TOHC_DEV void cvxLoad<1>(Cvx<1> &c, int kind, V3 dims, const float *, const float *, const float *, const F4 *v4, int voff, int n) {
+  c.kind = kind;
+  c.cast = 0;
+  c.n = n;
+  c.dims = dims;
+  c.v = v4 + voff;
 }
 
 TOHC_DEV float fsel(float a, float b, float c) { return a >= 0 ? b : c; }  // btScalar.h:468-473
@@ -112,6 +139,34 @@ TOHC_DEV V3 hullMaxDot(const Cvx<G> &c, V3 d) {
   for (int s = 1; s < Cvx<G>::VPL; ++s)
     if (s == slot) { sx = c.x[s]; sy = c.y[s]; sz = c.z[s]; }
   return mk(Grp<G>::bcast(sx, src), Grp<G>::bcast(sy, src), Grp<G>::bcast(sz, src));
+}
+
+template <>
+TOHC_DEV V3 hullMaxDot<1>(const Cvx<1> &c, V3 d) {
+  float best = -INFINITY;
+  V3 bv = mk(0, 0, 0);
+  for (int i = 0; i < c.n; ++i) {
+    const F4 p = c.v[i];
+    float dt = p.x * d.x + p.y * d.y + p.z * d.z;
+    if (dt > best) { best = dt; bv = mk(p.x, p.y, p.z); }
+  }
+  if (!(best > -INFINITY) && c.n > 0) { const F4 p = c.v[0]; bv = mk(p.x, p.y, p.z); }  // all-NaN dots: index 0, like the scan
+  return bv;
+}
+// vertex i of a hull, the same value in every lane of the group
+template <int G>
+TOHC_DEV V3 cvxVertex(const Cvx<G> &c, int i) {
+  const int slot = i / G, src = i % G;
+  float sx = c.x[0], sy = c.y[0], sz = c.z[0];
+#pragma unroll
+  for (int s = 1; s < Cvx<G>::VPL; ++s)
+    if (s == slot) { sx = c.x[s]; sy = c.y[s]; sz = c.z[s]; }
+  return mk(Grp<G>::bcast(sx, src), Grp<G>::bcast(sy, src), Grp<G>::bcast(sz, src));
+}
+template <>
+TOHC_DEV V3 cvxVertex<1>(const Cvx<1> &c, int i) {
+  const F4 p = c.v[i];
+  return mk(p.x, p.y, p.z);
 }
 
 // localGetSupportVertexWithoutMarginNonVirtual for box / hull [cvx:120-296]
@@ -661,7 +716,7 @@ struct Gjk2 {
   Mink<G> shape;
   V3 ray;
   float distance;
-  unsigned rank[2];
+  unsigned rank0, rank1;  // m_simplices[0/1].rank; two scalars + selects so that the struct stays in registers
   unsigned nfree, current;
   int status;
 
@@ -671,12 +726,19 @@ struct Gjk2 {
     st3(m->svw[sv], minkSupport<G>(shape, dn));
   }
   TOHC_DEV V3 W(unsigned s, unsigned i) const { return ld3(m->svw[m->sc[s][i]]); }
-  TOHC_DEV void remove(unsigned s) { m->freeL[nfree++] = m->sc[s][--rank[s]]; }
+  TOHC_DEV unsigned rk(unsigned s) const { return s ? rank1 : rank0; }
+  TOHC_DEV void setRk(unsigned s, unsigned v) { rank0 = s ? rank0 : v; rank1 = s ? v : rank1; }
+  TOHC_DEV void remove(unsigned s) {
+    const unsigned r = rk(s) - 1;
+    setRk(s, r);
+    m->freeL[nfree++] = m->sc[s][r];
+  }
   TOHC_DEV void append(unsigned s, V3 v) {
-    m->sp[s][rank[s]] = 0;
+    const unsigned r = rk(s);
+    m->sp[s][r] = 0;
     unsigned sv = m->freeL[--nfree];
-    m->sc[s][rank[s]] = (uint8_t)sv;
-    rank[s]++;
+    m->sc[s][r] = (uint8_t)sv;
+    setRk(s, r + 1);
     support(v, sv);
   }
 
@@ -691,7 +753,7 @@ struct Gjk2 {
     status = G2_VALID;
     shape = shapearg;
     distance = 0;
-    rank[0] = 0; rank[1] = 0;
+    rank0 = 0; rank1 = 0;
     ray = guess;
     float sqrl = len2(ray);
     append(0, sqrl > 0 ? -ray : mk(1, 0, 0));
@@ -705,7 +767,7 @@ struct Gjk2 {
       float rl = len(ray);
       if (rl < 0.0001f) { status = G2_INSIDE; break; }
       append(cs, -ray);
-      V3 w = W(cs, rank[cs] - 1);
+      V3 w = W(cs, rk(cs) - 1);
       bool found = false;
 #pragma unroll
       for (unsigned i = 0; i < 4; ++i)
@@ -720,29 +782,30 @@ struct Gjk2 {
       if (((rl - alpha) - (0.0001f * rl)) <= 0) { remove(current); break; }
       float weights[4] = {0, 0, 0, 0};
       unsigned mask = 0;
-      switch (rank[cs]) {
+      switch (rk(cs)) {
         case 2: sqdist = projOrigin2(W(cs, 0), W(cs, 1), weights, mask); break;
         case 3: sqdist = projOrigin3(W(cs, 0), W(cs, 1), W(cs, 2), weights, mask); break;
         case 4: sqdist = projOrigin4(W(cs, 0), W(cs, 1), W(cs, 2), W(cs, 3), weights, mask); break;
       }
       if (sqdist >= 0) {
-        rank[ns] = 0;
+        unsigned rn = 0;
         ray = mk(0, 0, 0);
         current = next;
-        for (unsigned i = 0, ni = rank[cs]; i < ni; ++i) {
+        for (unsigned i = 0, ni = rk(cs); i < ni; ++i) {
           float wi = weights[0];
 #pragma unroll
           for (unsigned k = 1; k < 4; ++k)
             if (k == i) wi = weights[k];
           if (mask & (1u << i)) {
-            m->sc[ns][rank[ns]] = m->sc[cs][i];
-            m->sp[ns][rank[ns]] = wi;
-            rank[ns]++;
+            m->sc[ns][rn] = m->sc[cs][i];
+            m->sp[ns][rn] = wi;
+            rn++;
             ray = ray + W(cs, i) * wi;
           } else {
             m->freeL[nfree++] = m->sc[cs][i];
           }
         }
+        setRk(ns, rn);
         if (mask == 15) status = G2_INSIDE;
       } else {
         remove(current);
@@ -764,7 +827,7 @@ struct Gjk2 {
     int lvl = 0;
     int cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
     for (;;) {
-      const unsigned r = rank[s];
+      const unsigned r = rk(s);
       if (r == 4) {
         if (fabsf(det3(W(s, 0) - W(s, 3), W(s, 1) - W(s, 3), W(s, 2) - W(s, 3))) > 0) return true;
         if (lvl == 0) return false;
@@ -965,7 +1028,7 @@ struct Epa {
 
   TOHC_DEV int evaluate(Gjk2<G> &g, V3 guess) {  // [epa:594-697]
     const unsigned s = g.current;
-    if ((g.rank[s] > 1) && g.encloseOrigin()) {
+    if ((g.rk(s) > 1) && g.encloseOrigin()) {
       while (hullRoot != TOHC_NIL) {
         unsigned f = hullRoot;
         removeF(hullRoot, hullCount, f);
@@ -1092,7 +1155,7 @@ TOHC_DEV bool calcPenDepth(EpaMem *mem, const Cvx<G> &A, const Cvx<G> &B, const 
     if (st == G2_VALID) {
       V3 a = mk(0, 0, 0), b = mk(0, 0, 0);
       const unsigned s = g.current;
-      for (unsigned i = 0; i < g.rank[s]; ++i) {
+      for (unsigned i = 0; i < g.rk(s); ++i) {
         float p = mem->sp[s][i];
         V3 d = ld3(mem->svd[mem->sc[s][i]]);
         a = a + minkSupport0<G>(shape, d) * p;
@@ -1175,12 +1238,7 @@ TOHC_DEV void averageSupport(const Cvx<G> &c, V3 nl, float &outsup, V3 &outpt) {
       pt = mk(he.x * (1 - (i & 1)) - he.x * (i & 1), he.y * (1 - ((i & 2) >> 1)) - he.y * ((i & 2) >> 1),
               he.z * (1 - ((i & 4) >> 2)) - he.z * ((i & 4) >> 2));
     } else {
-      const int slot = i / G, src = i % G;
-      float sx = c.x[0], sy = c.y[0], sz = c.z[0];
-#pragma unroll
-      for (int s = 1; s < Cvx<G>::VPL; ++s)
-        if (s == slot) { sx = c.x[s]; sy = c.y[s]; sz = c.z[s]; }
-      pt = mk(Grp<G>::bcast(sx, src), Grp<G>::bcast(sy, src), Grp<G>::bcast(sz, src));
+      pt = cvxVertex<G>(c, i);
     }
     float sup = dot(pt, nl);
     if (sup > maxS + EPS) { cnt = 1; sum = pt; maxS = sup; }
