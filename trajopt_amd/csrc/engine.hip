@@ -91,8 +91,8 @@ struct tohc_engine {
   // children that never move in each mode, with their cull boxes as an SoA table [6][n_stat_pad]
   std::vector<int> h_stat_childrenR, h_stat_childrenP;
   DBuf<int> d_stat_childrenR, d_stat_childrenP;
-  DBuf<float> d_stat_soaR, d_stat_soaP;
-  int n_statR = 0, n_stat_padR = 0;
+  DBuf<float> d_stat_soaR, d_stat_soaP, d_cl_soaR;
+  int n_statR = 0, n_stat_padR = 0, n_clR = 0, n_cl_padR = 0;
 
   // per-call buffers
   DBuf<double> d_dofs, d_linkQT, d_objQT, d_objQT1, d_grads;
@@ -197,7 +197,7 @@ void tohc_destroy(tohc_engine *e) {
   DBuf<float> *fb[] = {&e->d_shape_dims, &e->d_shape_lmin, &e->d_shape_lmax, &e->d_vx, &e->d_vy, &e->d_vz, &e->d_child_localT, &e->d_stat_xf,
                        &e->d_stat_aabb, &e->d_dynXf, &e->d_dynAabb, &e->d_dynXf1, &e->d_dynAabb1};
   for (auto b : fb) b->release();
-  e->d_v4.release();
+  e->d_v4.release(); e->d_cl_soaR.release(); e->d_stat_soaR.release(); e->d_stat_soaP.release();
   DBuf<double> *db[] = {&e->d_T_origin, &e->d_axis, &e->d_mult, &e->d_offs, &e->d_q_robot, &e->d_dofs, &e->d_linkQT, &e->d_objQT, &e->d_objQT1, &e->d_grads};
   for (auto b : db) b->release();
   e->d_allowed.release(); e->d_pairs.release(); e->d_epaq.release(); e->d_cnt.release(); e->d_records.release();
@@ -241,15 +241,62 @@ static int refreshStatic(tohc_engine *e) {
     HIPCHK(upload(e->d_child_desc, cd, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
   }
-  // SoA cull-box table of the children that never move in robot mode (everything until a robot is uploaded)
-  const std::vector<int> &st = e->h_stat_childrenR;
+  // SoA cull-box table of the children that never move in robot mode (everything until a robot is uploaded), in
+  // Morton order of the box centres so that 64 consecutive entries are neighbours in space, + one box per 64 entries
+  std::vector<int> st = e->h_stat_childrenR;
   e->n_statR = (int)st.size();
-  e->n_stat_padR = (e->n_statR + 63) / 64 * 64 + 64;
-  std::vector<float> soa((size_t)6 * e->n_stat_padR, 0.f);
-  for (int i = 0; i < e->n_statR; ++i)
-    for (int k = 0; k < 6; ++k) soa[(size_t)k * e->n_stat_padR + i] = bb[6 * (size_t)st[i] + k];
+  {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int c : st)
+      for (int k = 0; k < 3; ++k) {
+        float m = 0.5f * (bb[6 * (size_t)c + k] + bb[6 * (size_t)c + 3 + k]);
+        lo[k] = std::min(lo[k], m); hi[k] = std::max(hi[k], m);
+      }
+    auto spread = [](uint32_t v) {  // 10 bits -> every third bit
+      v &= 1023u;
+      v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu;
+      v = (v | (v << 4)) & 0x030C30C3u;  v = (v | (v << 2)) & 0x09249249u;
+      return v;
+    };
+    std::vector<std::pair<uint32_t, int>> keyed;
+    keyed.reserve(st.size());
+    for (int c : st) {
+      uint32_t code = 0;
+      for (int k = 0; k < 3; ++k) {
+        float m = 0.5f * (bb[6 * (size_t)c + k] + bb[6 * (size_t)c + 3 + k]);
+        float ext = hi[k] - lo[k];
+        float u = ext > 0 ? (m - lo[k]) / ext : 0.f;
+        if (!(u >= 0.f)) u = 0.f;   // also catches NaN
+        if (u > 1.f) u = 1.f;
+        code |= spread((uint32_t)(u * 1023.f)) << k;
+      }
+      keyed.push_back(std::make_pair(code, c));
+    }
+    std::sort(keyed.begin(), keyed.end());
+    for (size_t i = 0; i < st.size(); ++i) st[i] = keyed[i].second;
+  }
+  e->n_clR = (e->n_statR + 63) / 64;
+  e->n_stat_padR = std::max(e->n_clR, 1) * 64;
+  e->n_cl_padR = (e->n_clR + 63) / 64 * 64 + 64;
+  std::vector<float> soa((size_t)6 * e->n_stat_padR), cl((size_t)6 * e->n_cl_padR);
+  for (int k = 0; k < 6; ++k) {   // pads: inverted boxes, no closed-interval test can pass
+    std::fill(soa.begin() + (size_t)k * e->n_stat_padR, soa.begin() + (size_t)(k + 1) * e->n_stat_padR, k < 3 ? INFINITY : -INFINITY);
+    std::fill(cl.begin() + (size_t)k * e->n_cl_padR, cl.begin() + (size_t)(k + 1) * e->n_cl_padR, k < 3 ? INFINITY : -INFINITY);
+  }
+  for (int i = 0; i < e->n_statR; ++i) {
+    const int c = i / 64;
+    for (int k = 0; k < 6; ++k) {
+      const float v = bb[6 * (size_t)st[i] + k];
+      soa[(size_t)k * e->n_stat_padR + i] = v;
+      float &u = cl[(size_t)k * e->n_cl_padR + c];
+      u = k < 3 ? std::min(u, v) : std::max(u, v);
+    }
+  }
+  std::vector<int> stp(e->n_stat_padR, 0);
+  std::copy(st.begin(), st.end(), stp.begin());
   HIPCHK(upload(e->d_stat_soaR, soa, e->stream));
-  HIPCHK(upload(e->d_stat_childrenR, st.empty() ? std::vector<int>(1, 0) : st, e->stream));
+  HIPCHK(upload(e->d_cl_soaR, cl, e->stream));
+  HIPCHK(upload(e->d_stat_childrenR, stp, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   return TOHC_OK;
 }
@@ -489,6 +536,7 @@ static DynMap dynMapRobot(tohc_engine *e) {
   dm.obj_dyn = e->d_obj_dynR.p; dm.child_dyn = e->d_child_dynR.p; dm.n_dyn_obj = e->n_dyn_objR; dm.n_dyn_children = e->n_dyn_childrenR;
   dm.dyn_children = e->d_dyn_childrenR.p; dm.stat_children = e->d_stat_childrenR.p; dm.stat_soa = e->d_stat_soaR.p;
   dm.n_stat = e->n_statR; dm.n_stat_pad = e->n_stat_padR;
+  dm.cl_soa = e->d_cl_soaR.p; dm.n_cl = e->n_clR; dm.n_cl_pad = e->n_cl_padR;
   return dm;
 }
 static DynMap dynMapPoses(tohc_engine *e) {
@@ -496,6 +544,7 @@ static DynMap dynMapPoses(tohc_engine *e) {
   dm.obj_dyn = e->d_obj_dynP.p; dm.child_dyn = e->d_child_dynP.p; dm.n_dyn_obj = e->n_objects; dm.n_dyn_children = e->n_children;
   dm.dyn_children = e->d_dyn_childrenP.p; dm.stat_children = e->d_stat_childrenP.p; dm.stat_soa = e->d_stat_soaP.p;
   dm.n_stat = 0; dm.n_stat_pad = 64;
+  dm.cl_soa = e->d_stat_soaP.p; dm.n_cl = 0; dm.n_cl_pad = 64;
   return dm;
 }
 

@@ -49,8 +49,10 @@ struct DynMap {          // which objects / children move per set (robot links, 
   int n_dyn_obj, n_dyn_children;
   const int *dyn_children;   // [n_dyn_children] child ids
   const int *stat_children;  // [n_stat] child ids that never move in this mode
-  const float *stat_soa;     // [6][n_stat_pad] their cull boxes, SoA
+  const float *stat_soa;     // [6][n_stat_pad] their cull boxes, SoA, Morton order, padded to whole clusters of 64
   int n_stat, n_stat_pad;
+  const float *cl_soa;       // [6][n_cl_pad] box of each cluster of 64 consecutive table entries
+  int n_cl, n_cl_pad;
 };
 struct DevRobot {
   int n_links, K, n_joint_inds, affine;
@@ -285,17 +287,21 @@ __device__ __forceinline__ void loadSide(const NarrowArgs &a, int child, const C
 }
 
 // -----------------------------------------------------------------------------------------------------------------
-// k_broadphase: filters follow CollisionCollector::needsCollision (bullet_collision_checker.cpp:409-413) and
-// btSingleContactCallback::process (btCollisionWorld.cpp:1129-1137); the cull is the engine's own conservative box
-// test (same arithmetic as oracle/trajopt_oracle.c shapeAabb): both boxes grown by d, closed-interval overlap -- it
-// can never drop a pair whose distance is <= d.  Every box-test survivor is one PAIR EVALUATION (n_cand, what
-// tohc_counters.pair_evals reports, equal to the oracle's count).  The evaluation starts right here, while the query
-// child's shape sits in the block's registers: one support query along the line between the two origins bounds the
-// distance from below (sepAxisBeyond); pairs provably farther apart than d are finished, the rest go to k_gjk.
+// k_broadphase: ONE WAVEFRONT per (unit, query child).  Filters follow CollisionCollector::needsCollision
+// (bullet_collision_checker.cpp:409-413) and btSingleContactCallback::process (btCollisionWorld.cpp:1129-1137); the
+// cull is the engine's own conservative box test (same arithmetic as oracle/trajopt_oracle.c shapeAabb): both boxes
+// grown by d, closed-interval overlap -- it can never drop a pair whose distance is <= d.
+//   * children that never move sit in a Morton-ordered SoA table cut into clusters of 64 with a box per cluster
+//     (built on the host, refreshStatic): lane i tests cluster box i, then the wave scans only the clusters that
+//     overlap, 64 boxes per coalesced load -- the cull result is the same set as a full scan would give;
+//   * moving children (robot links; everything in "poses" mode) are scanned directly;
+//   * every box-test survivor is one PAIR EVALUATION (n_cand, what tohc_counters.pair_evals reports, equal to the
+//     oracle's count).  The evaluation starts right here, one lane per pair: one support query along the line between
+//     the two origins bounds the distance from below (sepAxisBeyond); pairs provably farther apart than d are
+//     finished, the rest go to k_gjk through the pair list (one atomic per drained queue, sharded).
 // -----------------------------------------------------------------------------------------------------------------
-#define TOHC_BP_THREADS 256
-#define TOHC_BP_CHUNK 2048
-#define TOHC_BP_G 16
+#define TOHC_BP_THREADS 64
+#define TOHC_BP_QCAP 256
 struct CullArgs {
   NarrowArgs a;
   const int *qchildren;
@@ -305,14 +311,12 @@ struct CullArgs {
 };
 template <bool CAST>
 __global__ void __launch_bounds__(TOHC_BP_THREADS) k_broadphase(CullArgs ca) {
-  constexpr int G = TOHC_BP_G;
   const NarrowArgs &a = ca.a;
   const DevScene &sc = a.sc;
   const DynMap &dm = a.dm;
   const CallParams &cp = a.cp;
-  __shared__ int s_hits[TOHC_BP_CHUNK];
-  __shared__ int s_surv[TOHC_BP_CHUNK];
-  __shared__ unsigned int s_n, s_m, s_base;
+  __shared__ int s_q[TOHC_BP_QCAP];
+  const int lane = threadIdx.x;
   const int qi = blockIdx.x % ca.nQ;
   const int cs = blockIdx.x / ca.nQ;
   const int q = ca.qchildren[qi];
@@ -324,84 +328,104 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS) k_broadphase(CullArgs ca) {
   Aabb bq = qs >= 0 ? ldAabb(ca.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + qs) * 6) : ldAabb(sc.stat_aabb + 6 * q);
   if (CAST && qs >= 0) bq = aabbUnion(bq, ldAabb(ca.dynAabb1 + ((size_t)set1 * dm.n_dyn_children + qs) * 6));
   const unsigned char *allowedRow = sc.allowed + (size_t)Q * sc.n_objects;
-  if (threadIdx.x == 0) { s_n = 0; s_m = 0; }
-  __syncthreads();
   const float lim = cp.d * 1.01f + 1.0e-4f;  // guard band: the bound and Bullet's result both carry ~1e-6 of rounding
+  unsigned int nq = 0, ncand = 0;            // wave-uniform
   bool haveQ = false;
-  Cvx<G> cq;
+  Cvx<1> cq;
   Xf tq;
-  // two passes: children that never move (SoA table, coalesced), then the moving ones (robot links / everything)
-  for (int pass = 0; pass < 2; ++pass) {
-    const int n = pass == 0 ? dm.n_stat : dm.n_dyn_children;
-    for (int base = 0; base < n; base += TOHC_BP_CHUNK) {
-      for (int i = base + threadIdx.x; i < min(n, base + TOHC_BP_CHUNK); i += TOHC_BP_THREADS) {
-        Aabb bx;
-        int x;
-        if (pass == 0) {
-          const float *t = dm.stat_soa + i;
-          const int P = dm.n_stat_pad;
-          bx.lo = mk(t[0], t[P], t[2 * P]);
-          bx.hi = mk(t[3 * P], t[4 * P], t[5 * P]);
-          if (!aabbOverlap(bq, bx)) continue;
-          x = dm.stat_children[i];
-        } else {
-          bx = ldAabb(ca.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + i) * 6);
-          if (!aabbOverlap(bq, bx)) continue;
-          x = dm.dyn_children[i];
-        }
-        const int X = sc.child_obj[x];
-        if (X == Q) continue;
-        const int gx = sc.obj_group[X];
-        if (CAST ? !(gx & TOHC_GROUP_KINBODY) : !(gx & (short)cp.filter_mask)) continue;  // cast: mask = KinBodyFilter (bcc:983)
-        if (!allowedRow[X]) continue;
-        s_hits[atomicAdd(&s_n, 1u)] = x;
-      }
-      __syncthreads();
-      const unsigned int nh = s_n;
-      if (nh > 0) {  // block-uniform
-        const int *out = s_hits;
-        unsigned int nout = nh;
+
+  // pre-test the queued box-test survivors, one lane per pair, and append what is left to the pair list
+  auto drain = [&]() {
+    __syncthreads();   // one wavefront per block: orders the queue writes before the reads below
+    ncand += nq;
+    if (ca.pretest && !haveQ) {
+      loadSide<1>(a, q, sc.child_desc[q], set0, set1, CAST, cq, tq);
+      haveQ = true;
+    }
+    for (unsigned int k0 = 0; k0 < nq; k0 += TOHC_BP_THREADS) {
+      const unsigned int k = k0 + lane;
+      bool keep = k < nq;
+      int x = 0;
+      if (keep) {
+        x = s_q[k];
         if (ca.pretest) {
-          if (!haveQ) {
-            loadSide<G>(a, q, sc.child_desc[q], set0, set1, CAST, cq, tq);
-            haveQ = true;
-          }
-          for (unsigned int k = threadIdx.x / G; k < nh; k += TOHC_BP_THREADS / G) {
-            const int x = s_hits[k];
-            Cvx<G> cx;
-            Xf tx;
-            loadSide<G>(a, x, sc.child_desc[x], set0, set1, false, cx, tx);
-            const V3 dir = tq.o - tx.o;
-            V3 w;
-            const bool far = (len2(dir) > 1.0e-12f) && sepAxisBeyond<G>(cq, cx, tq, tx, dir, lim, w);
-            if (!far && Grp<G>::lane() == 0) s_surv[atomicAdd(&s_m, 1u)] = x;
-          }
-          __syncthreads();
-          out = s_surv;
-          nout = s_m;
+          Cvx<1> cx;
+          Xf tx;
+          loadSide<1>(a, x, sc.child_desc[x], set0, set1, false, cx, tx);
+          const V3 dir = tq.o - tx.o;
+          V3 w;
+          keep = !((len2(dir) > 1.0e-12f) && sepAxisBeyond<1>(cq, cx, tq, tx, dir, lim, w));
         }
-        if (threadIdx.x == 0) {
-          atomicAdd(&a.cnt->n_cand[shard], nh);
-          if (nout > 0) s_base = atomicAdd(&a.cnt->n_pairs[shard], nout);
-        }
-        __syncthreads();
-        const unsigned int b0 = s_base;
-        for (unsigned int k = threadIdx.x; k < nout; k += TOHC_BP_THREADS) {
-          const unsigned int pos = b0 + k;
+      }
+      const unsigned long long m = __ballot(keep);
+      const unsigned int cnt = (unsigned int)__popcll(m);
+      if (cnt > 0) {
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(&a.cnt->n_pairs[shard], cnt);
+        base = __shfl(base, 0);
+        if (keep) {
+          const unsigned int pos = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
           if (pos < cp.seg_cap) {
             PairRec p;
-            p.set = cs; p.q = q; p.x = out[k]; p.pad = 0;
+            p.set = cs; p.q = q; p.x = x; p.pad = 0;
             a.pairs[(size_t)shard * cp.seg_cap + pos] = p;
           } else {
             a.cnt->overflow = 1;
           }
         }
-        __syncthreads();
-        if (threadIdx.x == 0) { s_n = 0; s_m = 0; }
-        __syncthreads();
       }
     }
+    __syncthreads();
+    nq = 0;
+  };
+  auto push = [&](bool hit, int x) {
+    if (hit) {  // object-level filters, only for boxes that overlap
+      const int X = sc.child_obj[x];
+      const int gx = sc.obj_group[X];
+      hit = (X != Q) && (CAST ? (gx & TOHC_GROUP_KINBODY) != 0 : (gx & (short)cp.filter_mask) != 0)  // cast: KinBodyFilter (bcc:983)
+            && allowedRow[X] != 0;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (hit) s_q[nq + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = x;
+    nq += (unsigned int)__popcll(m);
+    if (nq > TOHC_BP_QCAP - TOHC_BP_THREADS) drain();
+  };
+
+  // children that never move: cluster boxes first, then the members of the clusters that overlap
+  for (int cb = 0; cb < dm.n_cl; cb += TOHC_BP_THREADS) {
+    const int c = cb + lane;
+    bool over = false;
+    if (c < dm.n_cl) {
+      const float *t = dm.cl_soa + c;
+      const int P = dm.n_cl_pad;
+      Aabb bc;
+      bc.lo = mk(t[0], t[P], t[2 * P]);
+      bc.hi = mk(t[3 * P], t[4 * P], t[5 * P]);
+      over = aabbOverlap(bq, bc);
+    }
+    unsigned long long cm = __ballot(over);
+    while (cm) {
+      const int cc = cb + (int)__builtin_ctzll(cm);
+      cm &= cm - 1;
+      const int i = cc * 64 + lane;           // pad entries hold inverted boxes: they never overlap
+      const float *t = dm.stat_soa + i;
+      const int P = dm.n_stat_pad;
+      Aabb bx;
+      bx.lo = mk(t[0], t[P], t[2 * P]);
+      bx.hi = mk(t[3 * P], t[4 * P], t[5 * P]);
+      const bool hit = aabbOverlap(bq, bx);
+      push(hit, hit ? dm.stat_children[i] : 0);
+    }
   }
+  // moving children
+  for (int base = 0; base < dm.n_dyn_children; base += TOHC_BP_THREADS) {
+    const int i = base + lane;
+    bool hit = false;
+    if (i < dm.n_dyn_children) hit = aabbOverlap(bq, ldAabb(ca.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + i) * 6));
+    push(hit, hit ? dm.dyn_children[i] : 0);
+  }
+  if (nq > 0) drain();
+  if (lane == 0 && ncand > 0) atomicAdd(&a.cnt->n_cand[shard], ncand);
 }
 
 // Bullet's output filter [gjk:430-449] + the collector's distance filter (bullet_collision_checker.cpp:401)
