@@ -11,11 +11,13 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <numeric>
 #include <string>
 #include <vector>
 
 #include "../../include/trajopt_hipcc.h"
+#include "tohc_sort.h"
 #include "tohc_kernels.h"
 
 using namespace tohc;
@@ -101,7 +103,15 @@ struct tohc_engine {
   DBuf<EpaRec> d_epaq;
   DBuf<HitRec> d_hits;
   DBuf<Counters> d_cnt;            // [RING]
-  DBuf<tohc_record> d_records;
+  DBuf<tohc_record> d_records, d_sorted;
+  DBuf<double> d_gsorted;
+  DBuf<uint64_t> d_sort_keys;
+  DBuf<uint32_t> d_sort_idx;
+  DBuf<unsigned char> d_sort_tmp;
+  int last_T = 1;
+  bool children_in_object_order = true;   // obj_child_off is the running sum of obj_child_cnt (what the sort key assumes)
+  int64_t last_sets = 0;
+  bool host_sort = false;   // TOHC_HOST_SORT=1: order the slab on the host (the path taken anyway beyond the key's limits)
   HBuf<tohc_record> h_records, h_sorted;
   HBuf<double> h_grads, h_gsorted;
   HBuf<Counters> h_cnt;            // [RING]
@@ -173,6 +183,7 @@ int tohc_create(tohc_engine **out, int device) {
   const char *g = getenv("TOHC_GROUP");
   if (g && atoi(g) == 64) e->group = 64;
   if (const char *pt = getenv("TOHC_PRETEST")) e->pretest = atoi(pt) != 0;
+  if (const char *hs = getenv("TOHC_HOST_SORT")) e->host_sort = atoi(hs) != 0;
   e->gjk_group = e->group == 64 ? 64 : 1;
   if (const char *gg = getenv("TOHC_GJK_GROUP")) { int v = atoi(gg); if (v == 1 || v == 16 || v == 64) e->gjk_group = v; }
   e->breaking = (float)(2.001 * (double)e->d);
@@ -201,6 +212,7 @@ void tohc_destroy(tohc_engine *e) {
   DBuf<double> *db[] = {&e->d_T_origin, &e->d_axis, &e->d_mult, &e->d_offs, &e->d_q_robot, &e->d_dofs, &e->d_linkQT, &e->d_objQT, &e->d_objQT1, &e->d_grads};
   for (auto b : db) b->release();
   e->d_allowed.release(); e->d_pairs.release(); e->d_epaq.release(); e->d_cnt.release(); e->d_records.release();
+  e->d_sorted.release(); e->d_gsorted.release(); e->d_sort_keys.release(); e->d_sort_idx.release(); e->d_sort_tmp.release();
   e->h_records.release(); e->h_sorted.release(); e->h_grads.release(); e->h_gsorted.release(); e->h_cnt.release();
   (void)hipEventDestroy(e->ev0); (void)hipEventDestroy(e->ev1);
   for (auto ev : e->events) (void)hipEventDestroy(ev);
@@ -348,6 +360,8 @@ int tohc_upload_scene(tohc_engine *e, int n_shapes, const int32_t *shape_kind, c
     stXf(&e->h_child_localT[12 * c], xfFrom7(child_T + 7 * c));
   }
   e->h_obj_off.assign(obj_child_off, obj_child_off + n_objects); e->h_obj_cnt.assign(obj_child_cnt, obj_child_cnt + n_objects);
+  e->children_in_object_order = true;
+  for (int o = 0, run = 0; o < n_objects; ++o) { e->children_in_object_order &= obj_child_off[o] == run; run += obj_child_cnt[o]; }
   e->h_obj_compound.assign(obj_compound, obj_compound + n_objects); e->h_obj_group.assign(obj_group, obj_group + n_objects);
   e->h_obj_static_T.assign(obj_static_T, obj_static_T + (size_t)7 * n_objects);
   for (int o = 0; o < n_objects; ++o) {
@@ -671,6 +685,8 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
   e->pending.push_back(pd);
   e->last_robot_mode = robotMode;
   e->last_want_jac = robotMode && cp.want_jac;
+  e->last_T = cp.T;
+  e->last_sets = (int64_t)cp.T * ((cp.n_cast_sets + std::max(cp.T - cp.gap, 1) - 1) / std::max(cp.T - cp.gap, 1));
   return TOHC_OK;
 }
 
@@ -749,34 +765,57 @@ int tohc_fetch(tohc_engine *e, const tohc_record **records, const double **grads
   if (n == 0) return TOHC_OK;
   hipStream_t s = e->stream;
   const int K = e->last_robot_mode ? e->K : 1;
-  HIPCHK(e->h_records.reserve(n)); HIPCHK(e->h_sorted.reserve(n));
-  HIPCHK(hipMemcpyAsync(e->h_records.p, e->d_records.p, n * sizeof(tohc_record), hipMemcpyDeviceToHost, s));
   const bool haveG = e->last_want_jac;
-  if (haveG) {
-    HIPCHK(e->h_grads.reserve(n * 2 * K)); HIPCHK(e->h_gsorted.reserve(n * 2 * K));
-    HIPCHK(hipMemcpyAsync(e->h_grads.p, e->d_grads.p, n * 2 * K * sizeof(double), hipMemcpyDeviceToHost, s));
-  }
-  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(e->h_sorted.reserve(n));
+  if (haveG) HIPCHK(e->h_gsorted.reserve(n * 2 * K));
   // canonical order: Bullet's own order follows DBVT traversal and is history dependent.
   // discrete records (cctype none) sort before cast records of the same (problem, t) when both were appended.
-  std::vector<uint32_t> idx(n);
-  std::iota(idx.begin(), idx.end(), 0u);
-  const tohc_record *r = e->h_records.p;
-  std::sort(idx.begin(), idx.end(), [r](uint32_t i, uint32_t j) {
-    const tohc_record &a = r[i], &b = r[j];
-    if (a.problem != b.problem) return a.problem < b.problem;
-    if (a.t != b.t) return a.t < b.t;
-    const int ca = a.cctype != 0, cb = b.cctype != 0;
-    if (ca != cb) return ca < cb;
-    if (a.idA != b.idA) return a.idA < b.idA;
-    if (a.childA != b.childA) return a.childA < b.childA;
-    if (a.idB != b.idB) return a.idB < b.idB;
-    return a.childB < b.childB;
-  });
-  for (size_t i = 0; i < n; ++i) {
-    e->h_sorted.p[i] = r[idx[i]];
-    if (haveG) memcpy(e->h_gsorted.p + i * 2 * K, e->h_grads.p + (size_t)idx[i] * 2 * K, sizeof(double) * 2 * K);
+  const bool trace = getenv("TOHC_TRACE_FETCH") != nullptr;
+  auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_a = now();
+  const bool devSort = !e->host_sort && e->last_sets <= SORT_MAX_SETS && e->n_children <= SORT_MAX_CHILDREN && e->children_in_object_order;
+  if (devSort) {
+    size_t tmpBytes = 0;
+    HIPCHK(sortTempBytes(n, &tmpBytes));
+    HIPCHK(e->d_sort_tmp.reserve(tmpBytes)); HIPCHK(e->d_sort_keys.reserve(2 * n)); HIPCHK(e->d_sort_idx.reserve(2 * n));
+    HIPCHK(e->d_sorted.reserve(n));
+    if (haveG) HIPCHK(e->d_gsorted.reserve(n * 2 * K));
+    HIPCHK(sortRecords(e->d_records.p, haveG ? e->d_grads.p : nullptr, n, e->last_T, K, e->d_obj_off.p, e->d_sort_keys.p, e->d_sort_idx.p, e->d_sort_tmp.p, tmpBytes,
+                       e->d_sorted.p, haveG ? e->d_gsorted.p : nullptr, s));
+    if (trace) { HIPCHK(hipStreamSynchronize(s)); fprintf(stderr, "[fetch] device sort of %zu records: %.3f ms\n", n, now() - t_a); }
+    HIPCHK(hipMemcpyAsync(e->h_sorted.p, e->d_sorted.p, n * sizeof(tohc_record), hipMemcpyDeviceToHost, s));
+    if (haveG) HIPCHK(hipMemcpyAsync(e->h_gsorted.p, e->d_gsorted.p, n * 2 * K * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+  } else {
+    HIPCHK(e->h_records.reserve(n));
+    HIPCHK(hipMemcpyAsync(e->h_records.p, e->d_records.p, n * sizeof(tohc_record), hipMemcpyDeviceToHost, s));
+    if (haveG) {
+      HIPCHK(e->h_grads.reserve(n * 2 * K));
+      HIPCHK(hipMemcpyAsync(e->h_grads.p, e->d_grads.p, n * 2 * K * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    std::vector<uint32_t> idx(n);
+    std::iota(idx.begin(), idx.end(), 0u);
+    const tohc_record *r = e->h_records.p;
+    std::sort(idx.begin(), idx.end(), [r](uint32_t i, uint32_t j) {
+      const tohc_record &a = r[i], &b = r[j];
+      if (a.problem != b.problem) return a.problem < b.problem;
+      if (a.t != b.t) return a.t < b.t;
+      const int ca = a.cctype != 0, cb = b.cctype != 0;
+      if (ca != cb) return ca < cb;
+      if (a.idA != b.idA) return a.idA < b.idA;
+      if (a.childA != b.childA) return a.childA < b.childA;
+      if (a.idB != b.idB) return a.idB < b.idB;
+      return a.childB < b.childB;
+    });
+    for (size_t i = 0; i < n; ++i) {
+      e->h_sorted.p[i] = r[idx[i]];
+      if (haveG) memcpy(e->h_gsorted.p + i * 2 * K, e->h_grads.p + (size_t)idx[i] * 2 * K, sizeof(double) * 2 * K);
+    }
   }
+  if (trace)
+    fprintf(stderr, "[fetch] %s path (host_sort=%d sets=%lld children=%d), %zu records, K=%d: %.3f ms\n", devSort ? "device-sort" : "host-sort",
+            (int)e->host_sort, (long long)e->last_sets, e->n_children, n, K, now() - t_a);
   *n_records = (int)n;
   if (records) *records = e->h_sorted.p;
   if (grads) *grads = haveG ? e->h_gsorted.p : nullptr;
