@@ -4,6 +4,7 @@
 #include <cstring>
 #include <vector>
 
+#define TOHC_EMU_STATS 1
 #include "../../oracle/oracle_api.h"
 #include "../../trajopt_amd/csrc/tohc_narrow.h"
 
@@ -53,9 +54,23 @@ bool pairEval(World *w, const Cvx<1> &A, const Xf &tA, const Cvx<1> &B, const Xf
   g_iter_hist[st.iters < 63 ? st.iters : 63]++;
   g_epa_hist[st.needEpa ? 1 : 0]++;
   if (st.needEpa) {
+    // the two stages exactly as the device runs them: k_pen on a G2Mem, hand-over, k_epa on an EpaMem
     static EpaMem mem;
+    static G2Mem mem2;
     w->epa_evals++;
-    gjkFinishEpa<1>(&mem, A, B, tA, tB, st);
+    Xf lA, lB;
+    penLocal(tA, tB, st.offset, lA, lB);
+    V3 tmpA = mk(0, 0, 0), tmpB = mk(0, 0, 0), sep = mk(0, 0, 0);
+    bool isValid2 = false;
+    Gjk2<1, G2Mem> g1;
+    if (penStage1<1, G2Mem>(&mem2, A, B, lA, lB, g1, isValid2, sep, tmpA, tmpB)) {
+      PenHand h;
+      penSave<1, G2Mem>(h, g1);
+      Gjk2<1, EpaMem> g2;
+      penRestore<1>(&mem, h, A, B, lA, lB, g2);
+      penStage2<1>(&mem, lA, lB, g2, isValid2, sep, tmpA, tmpB);
+    }
+    gjkFinishTail(isValid2, sep, tmpA, tmpB, st);
   }
   PairOut o;
   gjkOutput(st, md, o);
@@ -198,6 +213,11 @@ int emu_cast_vs_all(void *h, const double *objT7, const int *q, int nq, const do
     }
   }
   return n;
+}
+long emu_stat(int i) {
+  const EmuStats &s = emuStats();
+  const long *p = &s.gjk2_calls;
+  return p[i];
 }
 long emu_pre(int i) { return g_pre[i]; }
 long emu_iter_hist(int i) { return g_iter_hist[i]; }

@@ -99,9 +99,22 @@ struct tohc_engine {
   // per-call buffers
   DBuf<double> d_dofs, d_linkQT, d_objQT, d_objQT1, d_grads;
   DBuf<float> d_dynXf, d_dynAabb, d_dynXf1, d_dynAabb1;
-  DBuf<PairRec> d_pairs;
-  DBuf<EpaRec> d_epaq;
-  DBuf<HitRec> d_hits;
+  // Enqueues alternate between NLANE lanes, each with its own HIP stream and queues, so that the discrete and the
+  // cast pass of one linearization (and consecutive enqueues in general) overlap on the GPU; only k_finish, which
+  // appends to the shared record slab, waits for the previous enqueue's.
+  struct Lane {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;       // recorded after the lane's latest k_bump
+    DBuf<PairRec> pairs;
+    DBuf<EpaRec> epaq;
+    DBuf<PenRec> penq;
+    DBuf<HitRec> hits;
+  };
+  Lane lane[2];
+  int n_lanes = 2;                   // TOHC_STREAMS=1: everything on one lane
+  hipEvent_t ev_fk = nullptr;        // the FK of the staged DOF vectors has finished (main stream)
+  bool fk_done = false;
+  DBuf<unsigned long long> d_dbg;   // TOHC_EPA_PROF builds only
   DBuf<Counters> d_cnt;            // [RING]
   DBuf<tohc_record> d_records, d_sorted;
   DBuf<double> d_gsorted;
@@ -128,6 +141,7 @@ struct tohc_engine {
   bool last_robot_mode = true, last_want_jac = false;
   size_t fetched_n = 0;
   int gjk_group = 1;  // lanes per pair in k_gjk: 1 (default), 16 or 64 (TOHC_GJK_GROUP)
+  int epa_block = 16;  // threads per k_epa block (TOHC_EPA_BLOCK = 16 or 64)
   int pretest = 1;   // TOHC_PRETEST=0 turns the separating-axis pre-test off (A/B measurements)
   tohc_engine() { memset(&counters, 0, sizeof counters); }
 };
@@ -142,6 +156,14 @@ static int fail(tohc_engine *e, int code, const char *fmt, ...) {
   va_end(ap);
   if (e) e->err = buf;
   return code;
+}
+
+// nothing may still be running on the lanes when tables they read are replaced
+static hipError_t quiesce(tohc_engine *e) {
+  for (auto &ln : e->lane)
+    if (ln.stream) { hipError_t r = hipStreamSynchronize(ln.stream); if (r != hipSuccess) return r; }
+  e->fk_done = false;
+  return hipStreamSynchronize(e->stream);
 }
 #define HIPCHK(call)                                                                                         \
   do {                                                                                                       \
@@ -183,6 +205,14 @@ int tohc_create(tohc_engine **out, int device) {
   const char *g = getenv("TOHC_GROUP");
   if (g && atoi(g) == 64) e->group = 64;
   if (const char *pt = getenv("TOHC_PRETEST")) e->pretest = atoi(pt) != 0;
+  if (const char *ns = getenv("TOHC_STREAMS")) e->n_lanes = atoi(ns) == 1 ? 1 : 2;
+  if (hipEventCreateWithFlags(&e->ev_fk, hipEventDisableTiming) != hipSuccess) { delete e; return TOHC_E_HIP; }
+  for (auto &ln : e->lane)
+    if (hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ln.done, hipEventDisableTiming) != hipSuccess) {
+      delete e;
+      return TOHC_E_HIP;
+    }
+  if (const char *eb = getenv("TOHC_EPA_BLOCK")) e->epa_block = atoi(eb) == 64 ? 64 : 16;
   if (const char *hs = getenv("TOHC_HOST_SORT")) e->host_sort = atoi(hs) != 0;
   e->gjk_group = e->group == 64 ? 64 : 1;
   if (const char *gg = getenv("TOHC_GJK_GROUP")) { int v = atoi(gg); if (v == 1 || v == 16 || v == 64) e->gjk_group = v; }
@@ -199,6 +229,12 @@ int tohc_create(tohc_engine **out, int device) {
 void tohc_destroy(tohc_engine *e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
+  for (auto &ln : e->lane) {
+    if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
+    if (ln.done) (void)hipEventDestroy(ln.done);
+    ln.pairs.release(); ln.epaq.release(); ln.penq.release(); ln.hits.release();
+  }
+  if (e->ev_fk) (void)hipEventDestroy(e->ev_fk);
   (void)hipStreamSynchronize(e->stream);
   DBuf<int> *ib[] = {&e->d_shape_kind, &e->d_shape_voff, &e->d_shape_vcnt, &e->d_child_shape, &e->d_child_obj, &e->d_child_idx, &e->d_obj_off,
                      &e->d_obj_cnt, &e->d_obj_compound, &e->d_obj_group, &e->d_parent, &e->d_jtype, &e->d_dof, &e->d_dof_col, &e->d_link_dyn,
@@ -211,7 +247,7 @@ void tohc_destroy(tohc_engine *e) {
   e->d_v4.release(); e->d_cl_soaR.release(); e->d_stat_soaR.release(); e->d_stat_soaP.release();
   DBuf<double> *db[] = {&e->d_T_origin, &e->d_axis, &e->d_mult, &e->d_offs, &e->d_q_robot, &e->d_dofs, &e->d_linkQT, &e->d_objQT, &e->d_objQT1, &e->d_grads};
   for (auto b : db) b->release();
-  e->d_allowed.release(); e->d_pairs.release(); e->d_epaq.release(); e->d_cnt.release(); e->d_records.release();
+  e->d_allowed.release(); e->d_dbg.release(); e->d_cnt.release(); e->d_records.release();
   e->d_sorted.release(); e->d_gsorted.release(); e->d_sort_keys.release(); e->d_sort_idx.release(); e->d_sort_tmp.release();
   e->h_records.release(); e->h_sorted.release(); e->h_grads.release(); e->h_gsorted.release(); e->h_cnt.release();
   (void)hipEventDestroy(e->ev0); (void)hipEventDestroy(e->ev1);
@@ -322,6 +358,7 @@ int tohc_upload_scene(tohc_engine *e, int n_shapes, const int32_t *shape_kind, c
       !obj_child_cnt || !obj_compound || !obj_group || !obj_static_T)
     return fail(e, TOHC_E_INVALID, "upload_scene: null or empty input");
   HIPCHK(hipSetDevice(e->device));
+  HIPCHK(quiesce(e));
   e->n_shapes = n_shapes; e->n_children = n_children; e->n_objects = n_objects; e->n_verts = n_verts;
   e->h_shape_kind.assign(shape_kind, shape_kind + n_shapes);
   e->h_shape_voff.assign(n_shapes, 0); e->h_shape_vcnt.assign(n_shapes, 0);
@@ -417,6 +454,7 @@ int tohc_upload_robot(tohc_engine *e, int n_links, const int32_t *parent, const 
     return fail(e, TOHC_E_INVALID, "upload_robot: null or empty input");
   if (affine & ~15) return fail(e, TOHC_E_UNSUPPORTED, "upload_robot: only DOF_X|DOF_Y|DOF_Z|DOF_RotationAxis affine DOFs are supported");
   HIPCHK(hipSetDevice(e->device));
+  HIPCHK(quiesce(e));
   e->n_links = n_links; e->n_joint_inds = n_joint_inds; e->affine = affine; e->n_dof = n_dof;
   e->K = n_joint_inds + ((affine & 1) != 0) + ((affine & 2) != 0) + ((affine & 4) != 0) + ((affine & 8) != 0);
   if (e->K <= 0) return fail(e, TOHC_E_INVALID, "upload_robot: no active degrees of freedom");
@@ -490,6 +528,7 @@ int tohc_set_allowed_matrix(tohc_engine *e, int n_objects, const uint8_t *allowe
   if (!e->have_scene) return fail(e, TOHC_E_STATE, "set_allowed_matrix: upload the scene first");
   if (n_objects != e->n_objects || !allowed) return fail(e, TOHC_E_INVALID, "set_allowed_matrix: expected a %d x %d matrix", e->n_objects, e->n_objects);
   HIPCHK(hipSetDevice(e->device));
+  HIPCHK(quiesce(e));
   e->h_allowed.assign(allowed, allowed + (size_t)n_objects * n_objects);
   HIPCHK(upload(e->d_allowed, e->h_allowed, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -499,6 +538,8 @@ int tohc_set_allowed_matrix(tohc_engine *e, int n_objects, const uint8_t *allowe
 int tohc_set_contact_distance(tohc_engine *e, float d) {
   if (!e) return TOHC_E_INVALID;
   if (!(d >= 0)) return fail(e, TOHC_E_INVALID, "set_contact_distance: negative or NaN distance");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(quiesce(e));
   e->d = d;
   e->breaking = (float)(2.001 * (double)d);  // gContactBreakingThreshold, bullet_collision_checker.cpp:453
   if (e->have_scene) {
@@ -511,6 +552,8 @@ double tohc_get_contact_distance(const tohc_engine *e) { return e ? (double)e->d
 
 int tohc_set_capacity(tohc_engine *e, int64_t max_pairs, int64_t max_records) {
   if (!e || max_pairs < 1 || max_records < 1 || max_pairs > ((int64_t)1 << 30) || max_records > ((int64_t)1 << 30)) return TOHC_E_INVALID;
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(quiesce(e));   // the queues are re-allocated at the next enqueue
   e->max_pairs = (size_t)max_pairs;
   e->max_records = (size_t)max_records;
   return TOHC_OK;
@@ -567,6 +610,7 @@ static DynMap dynMapPoses(tohc_engine *e) {
 // -----------------------------------------------------------------------------------------------------------------
 static int syncEngine(tohc_engine *e) {
   hipStream_t s = e->stream;
+  for (auto &ln : e->lane) HIPCHK(hipStreamSynchronize(ln.stream));
   if (e->pending.empty()) { HIPCHK(hipStreamSynchronize(s)); return TOHC_OK; }
   HIPCHK(hipMemcpyAsync(e->h_cnt.p, e->d_cnt.p, sizeof(Counters) * RING, hipMemcpyDeviceToHost, s));
   HIPCHK(hipMemcpyAsync(e->h_nrec.p, e->d_nrec.p, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
@@ -582,7 +626,7 @@ static int syncEngine(tohc_engine *e) {
     unsigned int np = 0, ne = 0, ng = 0;
     overflow |= k.overflow != 0;
     for (int sh = 0; sh < TOHC_NSHARD; ++sh) {
-      overflow |= k.n_pairs[sh] > segCap || k.n_epa[sh] > segCap || k.n_hits[sh] > segCap;
+      overflow |= k.n_pairs[sh] > segCap || k.n_epa[sh] > segCap || k.n_hits[sh] > segCap || k.n_pen[sh] > segCap / TOHC_PEN_DIV;
       np += k.n_cand[sh]; ng += k.n_pairs[sh]; ne += k.n_epa[sh];
     }
     worst_pairs = std::max(worst_pairs, ng);
@@ -593,9 +637,24 @@ static int syncEngine(tohc_engine *e) {
     for (int i = 0; i < NEV - 1; ++i) HIPCHK(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
     c.cum_ms_fk += ms[0]; c.cum_ms_children += ms[1]; c.cum_ms_broadphase += ms[2]; c.cum_ms_gjk += ms[3]; c.cum_ms_epa += ms[4];
     c.cum_ms_finish += ms[5];
-    c.ms_last_call += ms[0] + ms[1] + ms[2] + ms[3] + ms[4] + ms[5];
+    // enqueues overlap on the lanes: the device time of the call is the span from the first start to the last end
+    float span = 0;
+    HIPCHK(hipEventElapsedTime(&span, e->events[(size_t)e->pending.front().slot * NEV], ev[NEV - 1]));
+    c.ms_last_call = std::max(c.ms_last_call, (double)span);
     c.cum_launches += 1;
   }
+#if defined(TOHC_EPA_PROF)
+  if (e->d_dbg.p) {
+    unsigned long long h[32];
+    HIPCHK(hipMemcpy(h, e->d_dbg.p, sizeof h, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(e->d_dbg.p, 0, sizeof h));
+    if (h[0]) {
+      fprintf(stderr, "[epa prof] evals %llu  mean wall %.2f us  max wall %.2f us  mean cycles %.0f\n", h[0], h[1] / (double)h[0] / 100.0, h[3] / 100.0, h[2] / (double)h[0]);
+      const char *nm[8] = {"init", "support", "expand(x3)", "findbest", "enclose", "newface x4", "evaluate", "-"};
+      for (int k = 0; k < 7; ++k) fprintf(stderr, "   %-12s calls/eval %.2f  cycles/eval %.0f  cycles/call %.0f\n", nm[k], h[16 + k] / (double)h[0], h[8 + k] / (double)h[0], h[16 + k] ? h[8 + k] / (double)h[16 + k] : 0.0);
+    }
+  }
+#endif
   e->pending.clear();
   const unsigned int nrec = *e->h_nrec.p;
   c.contacts = nrec;
@@ -626,14 +685,23 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
                         bool robotMode, int slot, bool append) {
   const int nQ = (int)h_qchildren.size();
   const int K = robotMode ? e->K : 1;
-  hipStream_t s = e->stream;
+  tohc_engine::Lane &ln = e->lane[slot % e->n_lanes];
+  tohc_engine::Lane *prev = slot > 0 ? &e->lane[(slot - 1) % e->n_lanes] : nullptr;   // the enqueue before this one, if it is still pending
+  hipStream_t s = ln.stream;
   hipEvent_t *ev = &e->events[(size_t)slot * NEV];
+  HIPCHK(hipStreamWaitEvent(s, e->ev_fk, 0));   // pose tables of this call (FK / k_dyn_children on the main stream)
+  // a new slab starts only after everything that wrote the old one
+  if (!append && prev && prev != &ln) HIPCHK(hipStreamWaitEvent(s, prev->done, 0));
   HIPCHK(hipMemsetAsync(e->d_cnt.p + slot, 0, sizeof(Counters), s));
   if (!append) HIPCHK(hipMemsetAsync(e->d_nrec.p, 0, sizeof(unsigned int), s));
   cp.seg_cap = (unsigned int)(e->max_pairs / TOHC_NSHARD); cp.max_records = (unsigned int)e->max_records;
   cp.dbg_max_iter = getenv("TOHC_DBG_MAXITER") ? atoi(getenv("TOHC_DBG_MAXITER")) : 1000;
   const size_t qcap = (size_t)cp.seg_cap * TOHC_NSHARD;
-  HIPCHK(e->d_pairs.reserve(qcap)); HIPCHK(e->d_epaq.reserve(qcap)); HIPCHK(e->d_hits.reserve(qcap));
+  HIPCHK(ln.pairs.reserve(qcap)); HIPCHK(ln.epaq.reserve(qcap)); HIPCHK(ln.hits.reserve(qcap));
+  HIPCHK(ln.penq.reserve((size_t)(cp.seg_cap / TOHC_PEN_DIV) * TOHC_NSHARD));
+#if defined(TOHC_EPA_PROF)
+  if (!e->d_dbg.p) { HIPCHK(e->d_dbg.reserve(32)); HIPCHK(hipMemset(e->d_dbg.p, 0, 32 * sizeof(unsigned long long))); }
+#endif
   HIPCHK(e->d_records.reserve(e->max_records));
   HIPCHK(e->d_grads.reserve(e->max_records * 2 * (size_t)K));
   HIPCHK(hipEventRecord(ev[2], s));
@@ -647,8 +715,8 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
     a.dynXf0 = e->d_dynXf.p; a.dynXf1 = sep1 ? e->d_dynXf1.p : e->d_dynXf.p;
     a.linkQT = robotMode ? e->d_linkQT.p : nullptr;
     a.dofs = robotMode ? e->d_dofs.p : nullptr;
-    a.pairs = e->d_pairs.p; a.epaq = e->d_epaq.p; a.hits = e->d_hits.p; a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p;
-    a.records = e->d_records.p; a.grads = e->d_grads.p;
+    a.pairs = ln.pairs.p; a.epaq = ln.epaq.p; a.penq = ln.penq.p; a.hits = ln.hits.p; a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p;
+    a.records = e->d_records.p; a.grads = e->d_grads.p; a.dbg = e->d_dbg.p;
     CullArgs ca;
     ca.a = a; ca.qchildren = d_qchildren; ca.nQ = nQ;
     ca.dynAabb0 = e->d_dynAabb.p; ca.dynAabb1 = sep1 ? e->d_dynAabb1.p : e->d_dynAabb.p;
@@ -668,9 +736,14 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
       else hipLaunchKernelGGL((k_gjk<16, false, 256>), dim3(gridN), dim3(256), 0, s, a);
     }
     HIPCHK(hipEventRecord(ev[4], s));
+    if (cp.cast) hipLaunchKernelGGL((k_pen<true>), dim3(gridN), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((k_pen<false>), dim3(gridN), dim3(64), 0, s, a);
     if (e->group == 64) hipLaunchKernelGGL((k_epa<64, 64>), dim3(gridN), dim3(64), 0, s, a);
+    else if (e->epa_block == 16) hipLaunchKernelGGL((k_epa<16, 16>), dim3(gridN * 4), dim3(16), 0, s, a);  // one group per wavefront
     else hipLaunchKernelGGL((k_epa<16, 64>), dim3(gridN), dim3(64), 0, s, a);
     HIPCHK(hipEventRecord(ev[5], s));
+    // k_finish appends to the shared slab at the count the previous enqueue's k_bump left
+    if (append && prev && prev != &ln) HIPCHK(hipStreamWaitEvent(s, prev->done, 0));
     if (e->group == 64) hipLaunchKernelGGL((k_finish<64>), dim3(256 * 2), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_finish<16>), dim3(256 * 2), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, s, e->d_cnt.p + slot, cp.seg_cap, e->d_nrec.p);
@@ -679,6 +752,7 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
   } else {
     for (int i = 3; i < NEV; ++i) HIPCHK(hipEventRecord(ev[i], s));
   }
+  HIPCHK(hipEventRecord(ln.done, s));
   tohc_engine::Pending pd;
   pd.slot = slot;
   pd.aabb_tests = countAabbTests(e, h_qchildren, cp);
@@ -705,6 +779,8 @@ int tohc_stage_dofs(tohc_engine *e, const double *dofs, int B, int T) {
   if (!dofs || B < 1 || T < 1) return fail(e, TOHC_E_INVALID, "dofs is null or B/T < 1");
   HIPCHK(hipSetDevice(e->device));
   const size_t n_sets = (size_t)B * T;
+  for (auto &ln : e->lane) HIPCHK(hipStreamSynchronize(ln.stream));   // enqueues still reading the old tables
+  e->fk_done = false;
   HIPCHK(upload(e->d_dofs, dofs, n_sets * e->K, e->stream));
   HIPCHK(e->d_linkQT.reserve(n_sets * e->n_links * 7));
   HIPCHK(e->d_objQT.reserve(n_sets * std::max(e->n_dyn_objR, 1) * 7));
@@ -725,13 +801,23 @@ static int enqueueRobot(tohc_engine *e, int gap, int cast, int filter_mask, int 
   if (rc != TOHC_OK) return rc;
   const int B = e->staged_B, T = e->staged_T;
   const size_t n_sets = (size_t)B * T;
-  hipStream_t s = e->stream;
   hipEvent_t *ev = &e->events[(size_t)slot * NEV];
-  HIPCHK(hipEventRecord(ev[0], s));
   DynMap dm = dynMapRobot(e);
-  hipLaunchKernelGGL(k_fk, dim3((unsigned)n_sets), dim3(64), (size_t)e->n_links * 7 * sizeof(double), s, devRobot(e), devScene(e), dm, e->d_dofs.p,
-                     (int)n_sets, e->d, e->d_linkQT.p, e->d_objQT.p, e->d_dynXf.p, e->d_dynAabb.p);
-  HIPCHK(hipEventRecord(ev[1], s));
+  // FK once per linearization: every enqueue that starts a new slab runs it; appended passes reuse its tables
+  if (!append || !e->fk_done) {
+    hipStream_t s = e->stream;
+    for (auto &ln : e->lane) HIPCHK(hipStreamWaitEvent(s, ln.done, 0));   // pending enqueues still read the tables
+    HIPCHK(hipEventRecord(ev[0], s));
+    hipLaunchKernelGGL(k_fk, dim3((unsigned)n_sets), dim3(64), (size_t)e->n_links * 7 * sizeof(double), s, devRobot(e), devScene(e), dm, e->d_dofs.p,
+                       (int)n_sets, e->d, e->d_linkQT.p, e->d_objQT.p, e->d_dynXf.p, e->d_dynAabb.p);
+    HIPCHK(hipEventRecord(ev[1], s));
+    HIPCHK(hipEventRecord(e->ev_fk, s));
+    e->fk_done = true;
+  } else {
+    hipStream_t ls = e->lane[slot % e->n_lanes].stream;
+    HIPCHK(hipEventRecord(ev[0], ls));
+    HIPCHK(hipEventRecord(ev[1], ls));
+  }
   CallParams cp;
   memset(&cp, 0, sizeof cp);
   cp.T = T; cp.gap = cast ? gap : 0; cp.cast = cast; cp.filter_mask = filter_mask; cp.want_jac = want_jac; cp.d = e->d; cp.breaking = e->breaking;
@@ -845,6 +931,7 @@ static int posesQuery(tohc_engine *e, const double *obj_T, const double *cast_T1
   if (!e->have_scene) return fail(e, TOHC_E_STATE, "upload the scene first");
   if (!obj_T || n_sets < 1 || n_query < 0 || (n_query > 0 && !query) || (cast && !cast_T1)) return fail(e, TOHC_E_INVALID, "null pose or query input");
   HIPCHK(hipSetDevice(e->device));
+  HIPCHK(quiesce(e));
   std::vector<int> qch;
   std::vector<char> seen(e->n_objects, 0);
   for (int i = 0; i < n_query; ++i) {
@@ -881,6 +968,8 @@ static int posesQuery(tohc_engine *e, const double *obj_T, const double *cast_T1
     hipLaunchKernelGGL(k_dyn_children, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, devScene(e), dm, e->d_objQT1.p,
                        n_sets, e->d, e->d_dynXf1.p, e->d_dynAabb1.p);
   }
+  HIPCHK(hipEventRecord(e->ev_fk, s));
+  e->fk_done = false;
   HIPCHK(hipStreamSynchronize(s));  // caller-owned / local host buffers may go away
   CallParams cp;
   memset(&cp, 0, sizeof cp);

@@ -9,7 +9,9 @@
 //                   NSHARD counters (a single word saturates at ~88 atomics/us, MI355X_MICROARCH.md "dequeue")
 //   k_gjk           one group of G lanes per pair: GJK closest points (tohc_narrow.h); separated pairs that pass the
 //                   contact filter go to the hit list, penetrating / degenerate ones to the EPA queue
-//   k_epa           GJK2 + EPA with pools in LDS for the queued pairs -> hit list
+//   k_pen           the queued pairs, one lane per pair: GJK2 of the penetration solver; origin outside -> Distance
+//                   fall-back, done; origin inside -> on to k_epa with the GJK2 state
+//   k_epa           EPA proper, one group of 16 lanes per pair, face / vertex pools in LDS -> hit list
 //   k_finish        one group per hit: cast classification, record write, fused Jacobian rows (fp64); the p-th hit
 //                   becomes record base+p, so no atomics here
 // All queues are sharded NSHARD ways by producer block; consumers walk them through a 16-entry prefix.
@@ -66,8 +68,11 @@ struct DevRobot {
 struct PairRec { int set, q, x, pad; };
 struct EpaRec { int pair; int isValid; float distance; float n[3]; float pB[3]; };
 struct HitRec { int pair; float distance; float n[3]; float pB[3]; };
+struct PenRec { EpaRec e; PenHand h; };   // k_pen -> k_epa
+#define TOHC_PEN_DIV 8                     // the k_pen -> k_epa queue holds 1/8 of the pair capacity
 struct Counters {  // one per enqueue
   unsigned int n_pairs[TOHC_NSHARD], n_epa[TOHC_NSHARD], n_hits[TOHC_NSHARD];
+  unsigned int n_pen[TOHC_NSHARD];   // pairs k_pen hands to k_epa (origin inside the Minkowski difference)
   unsigned int n_cand[TOHC_NSHARD];  // box-test survivors = pair evaluations; n_pairs = those the pre-test passes on to k_gjk
   unsigned int overflow, pad[15];
 };
@@ -247,11 +252,13 @@ struct NarrowArgs {
   const double *dofs;     // [n_sets][K]
   PairRec *pairs;
   EpaRec *epaq;
+  PenRec *penq;
   HitRec *hits;
   Counters *cnt;
   unsigned int *n_records;   // records already in the slab (append) -- bumped by k_bump
   tohc_record *records;
   double *grads;             // [max_records][2][K]
+  unsigned long long *dbg;   // diagnostics (TOHC_EPA_PROF builds), else null
 };
 
 struct PairIds {
@@ -532,42 +539,112 @@ __global__ void __launch_bounds__(BLOCK, 2) k_gjk(NarrowArgs a) {
   }
 }
 
+// both operands of a queued pair in their GJK roles + the GJK result so far
+template <int G>
+__device__ __forceinline__ void loadQueued(const NarrowArgs &a, const EpaRec &e, bool cast, Cvx<G> &A, Cvx<G> &B, Xf &tA, Xf &tB, GjkState &st) {
+  const PairRec pr = a.pairs[e.pair];
+  const ChildDesc dq = a.sc.child_desc[pr.q], dx = a.sc.child_desc[pr.x];
+  int set0, set1;
+  castSets(a.cp, pr.set, set0, set1);
+  if (dx.compound) {
+    loadSide<G>(a, pr.x, dx, set0, set1, false, A, tA);
+    loadSide<G>(a, pr.q, dq, set0, set1, cast, B, tB);
+  } else {
+    loadSide<G>(a, pr.q, dq, set0, set1, cast, A, tA);
+    loadSide<G>(a, pr.x, dx, set0, set1, false, B, tB);
+  }
+  st.isValid = e.isValid != 0;
+  st.needEpa = true;
+  st.distance = e.distance;
+  st.normalInB = mk(e.n[0], e.n[1], e.n[2]);
+  st.pointOnB = mk(e.pB[0], e.pB[1], e.pB[2]);
+  st.offset = (tA.o + tB.o) * 0.5f;
+  st.iters = 0;
+}
+
+// k_pen: first stage of calcPenDepth for the pairs k_gjk queued, ONE LANE per pair: GJK2 needs only four support
+// vertices, so its whole state fits a 140-byte LDS record per lane.  Pairs whose origin lies inside the Minkowski
+// difference go on to k_epa with that state (PenRec); for the rest the Distance fall-back runs here and the pair is
+// finished.
+template <bool CAST>
+__global__ void __launch_bounds__(64, 2) k_pen(NarrowArgs a) {
+  __shared__ G2Mem mem[64];
+  const unsigned int gid = blockIdx.x * 64 + threadIdx.x;
+  const unsigned int nlanes = gridDim.x * 64;
+  QPrefix pre;
+  qprefix(a.cnt->n_epa, a.cp.seg_cap, pre);
+  const unsigned int nepa = pre.start[TOHC_NSHARD];
+  float md2 = a.cp.breaking;
+  md2 *= md2;
+  const unsigned int cap2 = a.cp.seg_cap / TOHC_PEN_DIV;
+  for (unsigned int i = gid; i < nepa; i += nlanes) {
+    const EpaRec e = a.epaq[qlocate(pre, a.cp.seg_cap, i)];
+    Cvx<1> A, B;
+    Xf tA, tB, lA, lB;
+    GjkState st;
+    loadQueued<1>(a, e, CAST, A, B, tA, tB, st);
+    penLocal(tA, tB, st.offset, lA, lB);
+    V3 tmpA = mk(0, 0, 0), tmpB = mk(0, 0, 0), sep = mk(0, 0, 0);
+    bool isValid2 = false;
+    Gjk2<1, G2Mem> g;
+    if (penStage1<1, G2Mem>(&mem[threadIdx.x], A, B, lA, lB, g, isValid2, sep, tmpA, tmpB)) {
+      const int shard = blockIdx.x % TOHC_NSHARD;
+      const unsigned int slot = atomicAdd(&a.cnt->n_pen[shard], 1u);
+      if (slot < cap2) {
+        PenRec *r = &a.penq[(size_t)shard * cap2 + slot];
+        r->e = e;
+        penSave<1, G2Mem>(r->h, g);
+      } else {
+        a.cnt->overflow = 1;
+      }
+    } else {
+      gjkFinishTail(isValid2, sep, tmpA, tmpB, st);
+      pushIfContact<1>(a, (unsigned int)e.pair, st, md2);
+    }
+  }
+}
+
+// k_epa: second stage (EPA proper) for the pairs k_pen handed over, one group of G lanes per pair, pools in LDS
 template <int G, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, 2) k_epa(NarrowArgs a) {
   __shared__ EpaMem mem[BLOCK / G];
   const int groupsPerBlock = BLOCK / G;
   const unsigned int gid = blockIdx.x * groupsPerBlock + threadIdx.x / G;
   const unsigned int ngroups = gridDim.x * groupsPerBlock;
+  const unsigned int cap2 = a.cp.seg_cap / TOHC_PEN_DIV;
   QPrefix pre;
-  qprefix(a.cnt->n_epa, a.cp.seg_cap, pre);
-  const unsigned int nepa = pre.start[TOHC_NSHARD];
+  qprefix(a.cnt->n_pen, cap2, pre);
+  const unsigned int npen = pre.start[TOHC_NSHARD];
   EpaMem *m = &mem[threadIdx.x / G];
   float md2 = a.cp.breaking;
   md2 *= md2;
-  for (unsigned int i = gid; i < nepa; i += ngroups) {
-    const EpaRec e = a.epaq[qlocate(pre, a.cp.seg_cap, i)];
-    const PairRec pr = a.pairs[e.pair];
-    const ChildDesc dq = a.sc.child_desc[pr.q], dx = a.sc.child_desc[pr.x];
-    int set0, set1;
-    castSets(a.cp, pr.set, set0, set1);
+  for (unsigned int i = gid; i < npen; i += ngroups) {
+    const PenRec *r = &a.penq[qlocate(pre, cap2, i)];
+    const EpaRec e = r->e;
     Cvx<G> A, B;
-    Xf tA, tB;
-    if (dx.compound) {
-      loadSide<G>(a, pr.x, dx, set0, set1, false, A, tA);
-      loadSide<G>(a, pr.q, dq, set0, set1, a.cp.cast != 0, B, tB);
-    } else {
-      loadSide<G>(a, pr.q, dq, set0, set1, a.cp.cast != 0, A, tA);
-      loadSide<G>(a, pr.x, dx, set0, set1, false, B, tB);
-    }
+    Xf tA, tB, lA, lB;
     GjkState st;
-    st.isValid = e.isValid != 0;
-    st.needEpa = true;
-    st.distance = e.distance;
-    st.normalInB = mk(e.n[0], e.n[1], e.n[2]);
-    st.pointOnB = mk(e.pB[0], e.pB[1], e.pB[2]);
-    st.offset = (tA.o + tB.o) * 0.5f;
-    st.iters = 0;
-    gjkFinishEpa<G>(m, A, B, tA, tB, st);
+    loadQueued<G>(a, e, a.cp.cast != 0, A, B, tA, tB, st);
+    penLocal(tA, tB, st.offset, lA, lB);
+    Gjk2<G, EpaMem> g;
+    penRestore<G>(m, r->h, A, B, lA, lB, g);
+    V3 tmpA = mk(0, 0, 0), tmpB = mk(0, 0, 0), sep = mk(0, 0, 0);
+    bool isValid2 = false;
+#if defined(TOHC_EPA_PROF)
+    const unsigned long long tw0 = wall_clock64(), tc0 = clock64();
+    EpaProf prof;
+    penStage2<G>(m, lA, lB, g, isValid2, sep, tmpA, tmpB, &prof);
+    if (Grp<G>::lane() == 0 && a.dbg) {
+      atomicAdd(&a.dbg[0], 1ull);
+      atomicAdd(&a.dbg[1], wall_clock64() - tw0);
+      atomicAdd(&a.dbg[2], clock64() - tc0);
+      atomicMax(&a.dbg[3], wall_clock64() - tw0);
+      for (int k = 0; k < 8; ++k) { atomicAdd(&a.dbg[8 + k], prof.t[k]); atomicAdd(&a.dbg[16 + k], (unsigned long long)prof.n[k]); }
+    }
+#else
+    penStage2<G>(m, lA, lB, g, isValid2, sep, tmpA, tmpB);
+#endif
+    gjkFinishTail(isValid2, sep, tmpA, tmpB, st);
     pushIfContact<G>(a, (unsigned int)e.pair, st, md2);
   }
 }

@@ -52,13 +52,32 @@ struct Grp {
 #pragma unroll
     for (int m = 16; m < G; m <<= 1) combine(v, i, __shfl_xor(v, m, G), __shfl_xor(i, m, G));
   }
-  static TOHC_DEV float sum_ordered(float v, int n) {  // sum of lanes' v over vertex order is not needed; placeholder
-    return v;
+  // (max value, MAX index) all-reduce
+  static TOHC_DEV void combineHi(float &v, int &i, float ov, int oi) {
+    bool take = (ov > v) || (ov == v && oi > i);
+    v = take ? ov : v;
+    i = take ? oi : i;
+  }
+  template <int CTRL>
+  static TOHC_DEV void dppStepHi(float &v, int &i) {
+    int vi = __float_as_int(v);
+    float ov = __int_as_float(__builtin_amdgcn_update_dpp(vi, vi, CTRL, 0xf, 0xf, false));
+    int oi = __builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, false);
+    combineHi(v, i, ov, oi);
+  }
+  static TOHC_DEV void argmax_hi(float &v, int &i) {
+    dppStepHi<0xB1>(v, i);
+    dppStepHi<0x4E>(v, i);
+    dppStepHi<0x141>(v, i);
+    dppStepHi<0x140>(v, i);
+#pragma unroll
+    for (int m = 16; m < G; m <<= 1) combineHi(v, i, __shfl_xor(v, m, G), __shfl_xor(i, m, G));
   }
 #else
   static int lane() { return 0; }
   static float bcast(float v, int) { return v; }
   static void argmax(float &, int &) {}
+  static void argmax_hi(float &, int &) {}
 #endif
 };
 
@@ -68,6 +87,7 @@ struct Grp<1> {  // one lane per pair: nothing to exchange
   static TOHC_DEV int lane() { return 0; }
   static TOHC_DEV float bcast(float v, int) { return v; }
   static TOHC_DEV void argmax(float &, int &) {}
+  static TOHC_DEV void argmax_hi(float &, int &) {}
 };
 #endif
 
@@ -586,8 +606,19 @@ struct EpaMem {
   uint8_t fe[TOHC_EPA_MAX_FACES][3];
   uint8_t fl[TOHC_EPA_MAX_FACES][2];
   uint8_t fpass[TOHC_EPA_MAX_FACES];
+  uint8_t fhull[TOHC_EPA_MAX_FACES];    // 1 while the face is on the hull list
+  uint16_t fstamp[TOHC_EPA_MAX_FACES];  // order of arrival on the hull list (the list is newest-first)
   uint8_t stF[TOHC_EPA_MAX_FACES], stE[TOHC_EPA_MAX_FACES], stS[TOHC_EPA_MAX_FACES];  // expand() stack
   // GJK2 simplices
+  uint8_t sc[2][4];
+  float sp[2][4];
+  uint8_t freeL[4];
+};
+
+// the part of EpaMem that GJK2 alone touches: one per LANE in the lane-per-pair penetration kernel (k_pen)
+struct G2Mem {
+  float svd[4][3];
+  float svw[4][3];
   uint8_t sc[2][4];
   float sp[2][4];
   uint8_t freeL[4];
@@ -709,10 +740,17 @@ TOHC_DEV float projOrigin4(V3 a, V3 b, V3 c, V3 d, float *w, unsigned &m) {  // 
 }
 
 enum { G2_VALID, G2_INSIDE, G2_FAILED };
+#if defined(TOHC_EMU_STATS)
+struct EmuStats { long gjk2_calls, gjk2_iters, epa_calls, epa_iters, epa_faces, enclose_appends, hist_epa[72], status[12], inside, hist_g2[130]; };
+inline EmuStats &emuStats() { static EmuStats s; return s; }
+#define TOHC_STAT(x) x
+#else
+#define TOHC_STAT(x)
+#endif
 
-template <int G>
+template <int G, class MEM>
 struct Gjk2 {
-  EpaMem *m;
+  MEM *m;
   Mink<G> shape;
   V3 ray;
   float distance;
@@ -813,6 +851,7 @@ struct Gjk2 {
       }
       status = ((++iterations) < 128) ? status : G2_FAILED;
     } while (status == G2_VALID);
+    TOHC_STAT(emuStats().gjk2_calls++; emuStats().gjk2_iters += iterations; emuStats().hist_g2[iterations < 129 ? iterations : 129]++; if (status == G2_INSIDE) emuStats().inside++;)
     switch (status) {
       case G2_VALID: distance = len(ray); break;
       case G2_INSIDE: distance = 0; break;
@@ -868,6 +907,17 @@ struct Gjk2 {
   }
 };
 
+// optional in-kernel profile of EPA (k_epa built with TOHC_EPA_PROF): cycle counts per phase, summed over evaluations
+#if defined(TOHC_EPA_PROF) && defined(__HIPCC__)
+struct EpaProf { unsigned long long t[8]; unsigned n[8]; };
+#define TOHC_PROF_T0(x) unsigned long long x = clock64()
+#define TOHC_PROF_ACC(p, k, x) do { (p).t[k] += clock64() - (x); (p).n[k]++; } while (0)
+#else
+struct EpaProf {};
+#define TOHC_PROF_T0(x)
+#define TOHC_PROF_ACC(p, k, x)
+#endif
+
 enum { E_VALID, E_TOUCHING, E_DEGENERATED, E_NONCONVEX, E_INVALIDHULL, E_OUTOFFACES, E_OUTOFVERTICES, E_ACCURACY, E_FALLBACK, E_FAILED };
 
 template <int G>
@@ -881,6 +931,8 @@ struct Epa {
   float depth;
   unsigned nextsv;
   unsigned hullRoot, hullCount, stockRoot, stockCount;
+  unsigned stamp;
+  EpaProf prof;
   // horizon
   unsigned hcf, hff, hnf;
 
@@ -903,14 +955,29 @@ struct Epa {
     if (f == root) root = l1;
     --count;
   }
+  TOHC_DEV void hullAppend(unsigned f) {
+    append(hullRoot, hullCount, f);
+    m->fhull[f] = 1;
+    m->fstamp[f] = (uint16_t)(++stamp);
+  }
+  TOHC_DEV void hullRemove(unsigned f) {
+    removeF(hullRoot, hullCount, f);
+    m->fhull[f] = 0;
+  }
   TOHC_DEV void init() {  // [epa:583-593]
     status = E_FAILED;
     normal = mk(0, 0, 0);
     depth = 0;
     nextsv = 0;
+    stamp = 0;
     hullRoot = TOHC_NIL; hullCount = 0;
-    stockRoot = TOHC_NIL; stockCount = 0;
-    for (unsigned i = 0; i < TOHC_EPA_MAX_FACES; ++i) append(stockRoot, stockCount, TOHC_EPA_MAX_FACES - i - 1);
+    // the reference pushes faces 127..0 onto the stock list one by one; the result is the list 0,1,...,127
+    for (unsigned f = (unsigned)Grp<G>::lane(); f < TOHC_EPA_MAX_FACES; f += G) {
+      m->fl[f][0] = (uint8_t)(f == 0 ? TOHC_NIL : f - 1);
+      m->fl[f][1] = (uint8_t)(f == TOHC_EPA_MAX_FACES - 1 ? TOHC_NIL : f + 1);
+      m->fhull[f] = 0;
+    }
+    stockRoot = 0; stockCount = TOHC_EPA_MAX_FACES;
   }
   TOHC_DEV bool getedgedist(V3 fnrm, V3 a, V3 b, float &dist) {  // [epa:698-733]
     V3 ba = b - a;
@@ -935,7 +1002,7 @@ struct Epa {
     if (stockRoot != TOHC_NIL) {
       unsigned face = stockRoot;
       removeF(stockRoot, stockCount, face);
-      append(hullRoot, hullCount, face);
+      hullAppend(face);
       m->fpass[face] = 0;
       m->fc[face][0] = (uint8_t)a; m->fc[face][1] = (uint8_t)b; m->fc[face][2] = (uint8_t)c;
       V3 aw = svW(a), bw = svW(b), cw = svW(c);
@@ -954,21 +1021,31 @@ struct Epa {
         st3(m->fn[face], n);
         status = E_DEGENERATED;
       }
-      removeF(hullRoot, hullCount, face);
+      hullRemove(face);
       append(stockRoot, stockCount, face);
       return TOHC_NIL;
     }
     status = E_OUTOFFACES;
     return TOHC_NIL;
   }
+  // findbest [epa:779-793] walks the hull list from its root (newest face first) and keeps the first strict
+  // minimum of d*d.  Same result without the pointer chase: every lane looks at its share of the face array, and
+  // among equal minima the newest face (largest stamp) wins.
   TOHC_DEV unsigned findbest() {
-    unsigned minf = hullRoot;
-    float mind = m->fd[minf] * m->fd[minf];
-    for (unsigned f = m->fl[minf][1]; f != TOHC_NIL; f = m->fl[f][1]) {
-      float sqd = m->fd[f] * m->fd[f];
-      if (sqd < mind) { minf = f; mind = sqd; }
+    const float rootD = m->fd[hullRoot];
+    float best = INFINITY;
+    int bkey = -1;   // (stamp << 8) | face; larger = earlier in the list
+    for (unsigned f = (unsigned)Grp<G>::lane(); f < TOHC_EPA_MAX_FACES; f += G) {
+      if (!m->fhull[f]) continue;
+      const float sqd = m->fd[f] * m->fd[f];
+      const int key = ((int)m->fstamp[f] << 8) | (int)f;
+      if (sqd < best || (sqd == best && key > bkey)) { best = sqd; bkey = key; }
     }
-    return minf;
+    // group-wide arg-min with the same tie rule: arg-max of (-d*d, key); a lane that saw nothing holds (-inf, -1)
+    float nb = -best;
+    Grp<G>::argmax_hi(nb, bkey);
+    if (!(rootD * rootD == rootD * rootD) || bkey < 0) return hullRoot;  // NaN at the root: no '<' ever succeeds
+    return (unsigned)(bkey & 255);
   }
   // expand [epa:794-827] on an explicit stack (stage 0: entry, 1: first child returned, 2: second child returned)
   TOHC_DEV bool expand(unsigned pass, unsigned w, unsigned f0, unsigned e0) {
@@ -1015,7 +1092,7 @@ struct Epa {
         }
       } else {
         if (ret) {
-          removeF(hullRoot, hullCount, f);
+          hullRemove(f);
           append(stockRoot, stockCount, f);
           ret = true;
         } else
@@ -1026,12 +1103,15 @@ struct Epa {
     return ret;
   }
 
-  TOHC_DEV int evaluate(Gjk2<G> &g, V3 guess) {  // [epa:594-697]
+  TOHC_DEV int evaluate(Gjk2<G, EpaMem> &g, V3 guess) {  // [epa:594-697]
     const unsigned s = g.current;
-    if ((g.rk(s) > 1) && g.encloseOrigin()) {
+    TOHC_PROF_T0(tenc);
+    const bool enclosed = (g.rk(s) > 1) && g.encloseOrigin();
+    TOHC_PROF_ACC(prof, 4, tenc);
+    if (enclosed) {
       while (hullRoot != TOHC_NIL) {
         unsigned f = hullRoot;
-        removeF(hullRoot, hullCount, f);
+        hullRemove(f);
         append(stockRoot, stockCount, f);
       }
       status = E_VALID;
@@ -1042,10 +1122,12 @@ struct Epa {
         m->sc[s][0] = (uint8_t)c0; m->sc[s][1] = (uint8_t)c1;
         float tp = m->sp[s][0]; m->sp[s][0] = m->sp[s][1]; m->sp[s][1] = tp;
       }
+      TOHC_PROF_T0(tnf);
       unsigned t0 = newface(c0, c1, c2, true);
       unsigned t1 = newface(c1, c0, c3, true);
       unsigned t2 = newface(c2, c1, c3, true);
       unsigned t3 = newface(c0, c2, c3, true);
+      TOHC_PROF_ACC(prof, 5, tnf);
       if (hullCount == 4) {
         unsigned best = findbest();
         V3 outerN = ld3(m->fn[best]);
@@ -1066,15 +1148,21 @@ struct Epa {
             bool valid = true;
             m->fpass[best] = (uint8_t)(++pass);
             V3 bn = ld3(m->fn[best]);
+            TOHC_PROF_T0(ts);
             g.support(bn, w);
+            TOHC_PROF_ACC(prof, 1, ts);
             float wdist = dot(bn, svW(w)) - m->fd[best];
             if (wdist > 0.0001f) {
+              TOHC_PROF_T0(te);
               for (unsigned j = 0; (j < 3) && valid; ++j) valid &= expand(pass, w, m->ff[best][j], m->fe[best][j]);
+              TOHC_PROF_ACC(prof, 2, te);
               if (valid && (hnf >= 3)) {
                 bind(hcf, 1, hff, 2);
-                removeF(hullRoot, hullCount, best);
+                hullRemove(best);
                 append(stockRoot, stockCount, best);
+                TOHC_PROF_T0(tf);
                 best = findbest();
+                TOHC_PROF_ACC(prof, 3, tf);
                 outerN = ld3(m->fn[best]);
                 outerD = m->fd[best];
                 oc0 = m->fc[best][0]; oc1 = m->fc[best][1]; oc2 = m->fc[best][2];
@@ -1082,6 +1170,8 @@ struct Epa {
             } else { status = E_ACCURACY; break; }
           } else { status = E_OUTOFVERTICES; break; }
         }
+        TOHC_STAT(emuStats().epa_calls++; emuStats().epa_iters += iterations; emuStats().epa_faces += hullCount;
+                  emuStats().hist_epa[iterations < 71 ? iterations : 71]++; emuStats().status[status]++;)
         V3 projection = outerN * outerD;
         normal = outerN;
         depth = outerD;
@@ -1116,60 +1206,81 @@ TOHC_DEV void minkInit(Mink<G> &m, const Cvx<G> *s0, const Xf &w0, const Cvx<G> 
   m.margins = margins;
 }
 
-// btGjkEpaPenetrationDepthSolver::calcPenDepth [pds:24-64] = Penetration [epa:903-945], else Distance [epa:865-900]
-template <int G>
-TOHC_DEV bool calcPenDepth(EpaMem *mem, const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &tB, V3 &v, V3 &wA, V3 &wB) {
+// btGjkEpaPenetrationDepthSolver::calcPenDepth [pds:24-64] = Penetration [epa:903-945], else Distance [epa:865-900],
+// cut into two stages so that the device can run them in different kernels:
+//   stage 1 (penStage1): the GJK2 of Penetration (with margins).  Origin not inside -> Distance's GJK2 (without) and
+//            the result is final.  Origin inside -> EPA is needed; the GJK2 state goes into a PenHand.
+//   stage 2 (penStage2): EPA from that state, witness points.
+struct PenHand {
+  G2Mem mem;
+  unsigned rank0, rank1, nfree, current;
+};
+template <class MA, class MB>
+TOHC_DEV void g2Copy(MA *dst, const MB *src) {
+  for (int i = 0; i < 4; ++i) {
+    for (int k = 0; k < 3; ++k) { dst->svd[i][k] = src->svd[i][k]; dst->svw[i][k] = src->svw[i][k]; }
+    dst->freeL[i] = src->freeL[i];
+    for (int q = 0; q < 2; ++q) { dst->sc[q][i] = src->sc[q][i]; dst->sp[q][i] = src->sp[q][i]; }
+  }
+}
+// returns true when EPA is needed (g holds the state); else isValid2 / v / wA / wB are final
+template <int G, class MEM>
+TOHC_DEV bool penStage1(MEM *mem, const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &tB, Gjk2<G, MEM> &g, bool &isValid2, V3 &v, V3 &wA, V3 &wB) {
   V3 guess = tA.o - tB.o;
   Mink<G> shape;
-  {
-    minkInit<G>(shape, &A, tA, &B, tB, true);
-    Gjk2<G> g;
-    g.m = mem;
-    int st = g.evaluate(shape, -guess);
-    if (st == G2_INSIDE) {
-      Epa<G> e;
-      e.m = mem;
-      e.init();
-      int es = e.evaluate(g, -guess);
-      if (es != E_FAILED) {
-        V3 w0 = mk(0, 0, 0);
-        for (unsigned i = 0; i < e.rrank; ++i) {
-          unsigned ci = e.rc[0];
-          float pi = e.rp[0];
-          if (i == 1) { ci = e.rc[1]; pi = e.rp[1]; }
-          if (i == 2) { ci = e.rc[2]; pi = e.rp[2]; }
-          w0 = w0 + minkSupport0<G>(shape, ld3(mem->svd[ci])) * pi;
-        }
-        wA = xfApply(tA, w0);
-        wB = xfApply(tA, w0 - e.normal * e.depth);
-        v = -e.normal;
-        return true;
-      }
+  isValid2 = false;
+  minkInit<G>(shape, &A, tA, &B, tB, true);
+  g.m = mem;
+  if (g.evaluate(shape, -guess) == G2_INSIDE) return true;
+  minkInit<G>(shape, &A, tA, &B, tB, false);
+  int st = g.evaluate(shape, guess);
+  if (st == G2_VALID) {
+    V3 a = mk(0, 0, 0), b = mk(0, 0, 0);
+    const unsigned s = g.current;
+    for (unsigned i = 0; i < g.rk(s); ++i) {
+      float p = mem->sp[s][i];
+      V3 d = ld3(mem->svd[mem->sc[s][i]]);
+      a = a + minkSupport0<G>(shape, d) * p;
+      b = b + minkSupport1<G>(shape, -d) * p;
     }
-  }
-  {
-    minkInit<G>(shape, &A, tA, &B, tB, false);
-    Gjk2<G> g;
-    g.m = mem;
-    int st = g.evaluate(shape, guess);
-    if (st == G2_VALID) {
-      V3 a = mk(0, 0, 0), b = mk(0, 0, 0);
-      const unsigned s = g.current;
-      for (unsigned i = 0; i < g.rk(s); ++i) {
-        float p = mem->sp[s][i];
-        V3 d = ld3(mem->svd[mem->sc[s][i]]);
-        a = a + minkSupport0<G>(shape, d) * p;
-        b = b + minkSupport1<G>(shape, -d) * p;
-      }
-      wA = xfApply(tA, a);
-      wB = xfApply(tA, b);
-      V3 nrm = a - b;
-      float dist = len(nrm);
-      v = vdiv(nrm, dist > 0.0001f ? dist : 1);
-      return false;
-    }
+    wA = xfApply(tA, a);
+    wB = xfApply(tA, b);
+    V3 nrm = a - b;
+    float dist = len(nrm);
+    v = vdiv(nrm, dist > 0.0001f ? dist : 1);
   }
   return false;
+}
+// g: the state penStage1 left (restored into an EpaMem when the stages run in different kernels)
+template <int G>
+TOHC_DEV void penStage2(EpaMem *mem, const Xf &tA, const Xf &tB, Gjk2<G, EpaMem> &g, bool &isValid2, V3 &v, V3 &wA, V3 &wB, EpaProf *prof = nullptr) {
+  V3 guess = tA.o - tB.o;
+  Epa<G> e;
+  e.m = mem;
+#if defined(TOHC_EPA_PROF) && defined(__HIPCC__)
+  for (int k = 0; k < 8; ++k) { e.prof.t[k] = 0; e.prof.n[k] = 0; }
+#endif
+  TOHC_PROF_T0(ti);
+  e.init();
+  TOHC_PROF_ACC(e.prof, 0, ti);
+  TOHC_PROF_T0(tev);
+  e.evaluate(g, -guess);  // never leaves E_FAILED: every path sets a status, so the reference's Distance fall-back is dead here
+  TOHC_PROF_ACC(e.prof, 6, tev);
+#if defined(TOHC_EPA_PROF) && defined(__HIPCC__)
+  if (prof) *prof = e.prof;
+#endif
+  V3 w0 = mk(0, 0, 0);
+  for (unsigned i = 0; i < e.rrank; ++i) {
+    unsigned ci = e.rc[0];
+    float pi = e.rp[0];
+    if (i == 1) { ci = e.rc[1]; pi = e.rp[1]; }
+    if (i == 2) { ci = e.rc[2]; pi = e.rp[2]; }
+    w0 = w0 + minkSupport0<G>(g.shape, ld3(mem->svd[ci])) * pi;
+  }
+  wA = xfApply(tA, w0);
+  wB = xfApply(tA, w0 - e.normal * e.depth);
+  v = -e.normal;
+  isValid2 = true;
 }
 
 // second half of getClosestPointsNonVirtual [gjk:334-449]: penetration / degenerate handling and the output filter
@@ -1179,13 +1290,8 @@ struct PairOut {
   float distance;
 };
 
-template <int G>
-TOHC_DEV void gjkFinishEpa(EpaMem *mem, const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &tB, GjkState &st) {
-  Xf lA = tA, lB = tB;
-  lA.o = lA.o - st.offset;
-  lB.o = lB.o - st.offset;
-  V3 tmpA = mk(0, 0, 0), tmpB = mk(0, 0, 0), sep = mk(0, 0, 0);
-  bool isValid2 = calcPenDepth<G>(mem, A, B, lA, lB, sep, tmpA, tmpB);
+// [gjk:349-416] what getClosestPointsNonVirtual does with calcPenDepth's answer
+TOHC_DEV void gjkFinishTail(bool isValid2, V3 sep, V3 tmpA, V3 tmpB, GjkState &st) {
   if (isValid2) {
     V3 tmpN = tmpB - tmpA;
     float lenSqr = len2(tmpN);
@@ -1208,6 +1314,41 @@ TOHC_DEV void gjkFinishEpa(EpaMem *mem, const Cvx<G> &A, const Cvx<G> &B, const 
       }
     }
   }
+}
+// the operand transforms calcPenDepth sees: shifted by the midpoint offset [gjk:112-115]
+TOHC_DEV void penLocal(const Xf &tA, const Xf &tB, V3 offset, Xf &lA, Xf &lB) {
+  lA = tA; lB = tB;
+  lA.o = lA.o - offset;
+  lB.o = lB.o - offset;
+}
+
+// hand-over between the stages when they run in different kernels
+template <int G, class MEM>
+TOHC_DEV void penSave(PenHand &h, const Gjk2<G, MEM> &g) {
+  g2Copy(&h.mem, g.m);
+  h.rank0 = g.rank0; h.rank1 = g.rank1; h.nfree = g.nfree; h.current = g.current;
+}
+template <int G>
+TOHC_DEV void penRestore(EpaMem *mem, const PenHand &h, const Cvx<G> &A, const Cvx<G> &B, const Xf &lA, const Xf &lB, Gjk2<G, EpaMem> &g) {
+  g2Copy(mem, &h.mem);
+  g.m = mem;
+  g.rank0 = h.rank0; g.rank1 = h.rank1; g.nfree = h.nfree; g.current = h.current;
+  g.status = G2_INSIDE;
+  g.distance = 0;
+  g.ray = mk(0, 0, 0);
+  minkInit<G>(g.shape, &A, lA, &B, lB, true);
+}
+
+// both stages back to back on one EpaMem (host emulation; the device runs k_pen then k_epa)
+template <int G>
+TOHC_DEV void gjkFinishEpa(EpaMem *mem, const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &tB, GjkState &st) {
+  Xf lA, lB;
+  penLocal(tA, tB, st.offset, lA, lB);
+  V3 tmpA = mk(0, 0, 0), tmpB = mk(0, 0, 0), sep = mk(0, 0, 0);
+  bool isValid2 = false;
+  Gjk2<G, EpaMem> g;
+  if (penStage1<G, EpaMem>(mem, A, B, lA, lB, g, isValid2, sep, tmpA, tmpB)) penStage2<G>(mem, lA, lB, g, isValid2, sep, tmpA, tmpB);
+  gjkFinishTail(isValid2, sep, tmpA, tmpB, st);
 }
 
 TOHC_DEV void gjkOutput(const GjkState &st, float maxDist2, PairOut &o) {
