@@ -24,17 +24,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# HBM bytes per launch from the PMC counters (profiles/, collected as MI355X_MICROARCH.md prescribes); None = not collected
+TRAFFIC_BYTES_PER_LAUNCH = {}
 
 
-def build_world(rank, problems, T=100):
-    from trajopt_amd import collision_checker as CC, synth
+def build_world(rank, world, problems, T=100):
+    """`problems` multi-start trajectories per GPU (weak scaling): the job's problems*world problems are numbered
+    job-wide, problem g is seeded with 1000+g, and rank r takes the block multi_gpu.partition gives it."""
+    from trajopt_amd import collision_checker as CC, multi_gpu, synth
     s, rb, static_T, d = synth.config_fullbody_soup()
     cc = CC.HIPCollisionChecker(s, static_T, None, device=rank_device(rank))
     cc.SetRobot(rb)                       # uploads + IgnoreZeroStateSelfCollisions, like the reference's AddKinBody path
     cc.SetContactDistance(d)
     cc.eng.set_capacity(1 << 23, 1 << 21)
-    rng = np.random.default_rng(1000 + rank)
-    dofs = np.stack([synth.fullbody_trajectory(rb, rng, T) for _ in range(problems)])
+    lo, hi = multi_gpu.partition(problems * world, world, rank)
+    dofs = np.stack([synth.fullbody_trajectory(rb, np.random.default_rng(1000 + g), T) for g in range(lo, hi)])
     return s, rb, static_T, d, cc, dofs
 
 
@@ -42,13 +46,14 @@ def rank_device(rank):
     return int(os.environ.get("LOCAL_RANK", rank))
 
 
-def cpu_baseline(s, rb, static_T, d, allowed, traj, budget_s=12.0):
-    """The CPU path on ONE host core, on a bounded sample of the same workload: timesteps of problem 0 taken with a
-    stride until ~budget_s of work.  kind=reference: the reference's own vendored Bullet (oracle/_ref) doing
+def cpu_baseline(s, rb, static_T, d, allowed, trajs, budget_s=12.0):
+    """The CPU path on ONE host core, on a bounded sample of the same workload: timesteps of the rank's problems, each
+    problem taken with a stride of 7, problem after problem until ~budget_s of work.  kind=reference: the reference's own vendored Bullet (oracle/_ref) doing
     LinksVsAll + CastVsAll on poses from the oracle's FK (FK / Jacobian time NOT charged to it);
     kind=port: the C restatement doing the full linearization."""
     from oracle import bindings as B
-    T = len(traj)
+    T = trajs.shape[1]
+    order = [(p, t) for p in range(len(trajs)) for t in list(range(0, T - 1, 7)) + [t for t in range(T - 1) if t % 7]]
     out = {}
     wo = B.oracle_world(s, cap=1 << 18)
     wo.set_contact_distance(d)
@@ -57,11 +62,11 @@ def cpu_baseline(s, rb, static_T, d, allowed, traj, budget_s=12.0):
     t0 = time.perf_counter()
     pe0 = wo.counter(0)
     used = 0
-    for t in list(range(0, T - 1, 7)) + [t for t in range(T - 1) if t % 7]:
-        wo.linearize(rb, static_T, traj[t:t + 1])
-        wo.linearize(rb, static_T, traj[t:t + 2], cast=True)
+    for p, t in order:
+        wo.linearize(rb, static_T, trajs[p, t:t + 1])
+        wo.linearize(rb, static_T, trajs[p, t:t + 2], cast=True)
         used += 1
-        if time.perf_counter() - t0 > budget_s:
+        if time.perf_counter() - t0 > budget_s / 2:   # the port is the secondary figure
             break
     dt = time.perf_counter() - t0
     out["port"] = dict(value=(wo.counter(0) - pe0) / dt, seconds=dt, timesteps=used)
@@ -82,9 +87,9 @@ def cpu_baseline(s, rb, static_T, d, allowed, traj, budget_s=12.0):
 
         g0 = lib.ref_gjk_checks()
         tsum, used = 0.0, 0
-        for t in list(range(0, T - 1, 7)) + [t for t in range(T - 1) if t % 7]:
-            P0, fk0 = poses(traj[t])
-            _, fk1 = poses(traj[t + 1])
+        for p, t in order:
+            P0, fk0 = poses(trajs[p, t])
+            _, fk1 = poses(trajs[p, t + 1])
             t0 = time.perf_counter()
             wr.links_vs_all(P0, objs)
             wr.cast_vs_all(P0, objs, fk0[links], fk1[links])
@@ -118,7 +123,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU: the engine has no CPU fallback"
 
     P, T = args.problems_per_gpu, 100
-    s, rb, static_T, d, cc, dofs = build_world(rank, P, T)
+    s, rb, static_T, d, cc, dofs = build_world(rank, world, P, T)
     eng = cc.eng
 
     def step():
@@ -145,15 +150,8 @@ def main():
     rec, grads = eng.fetch()
 
     pair_evals = c1["cum_pair_evals"] - c0["cum_pair_evals"]
-    tot = torch.tensor([dt, float(pair_evals)], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        tmax = tot[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        psum = tot[1:].clone()
-        dist.all_reduce(psum, op=dist.ReduceOp.SUM)
-        dt_max, pairs_all = float(tmax.item()), float(psum.item())
-    else:
-        dt_max, pairs_all = dt, float(pair_evals)
+    from trajopt_amd import multi_gpu
+    dt_max, pairs_all = multi_gpu.reduce_measurement(dt, pair_evals, dist, device="cuda")
 
     # PCIe-inclusive API rate on rank 0's data (never `value`)
     api = None
@@ -183,18 +181,34 @@ def main():
     if rank == 0:
         launches = c1["cum_launches"] - c0["cum_launches"]
         ms = {k: (c1["cum_ms_" + k] - c0["cum_ms_" + k]) / max(launches, 1) for k in ("fk", "children", "broadphase", "gjk", "epa", "finish")}
-        # roofline of the dominant kernel (k_gjk): algorithmic bytes per pair-eval (SURVEY.md 8d / DESIGN.md):
-        #   12*(nA+nB) vertices + 96 two fp32 3x4 transforms + [152 + 16*K if a record is written]
+        # roofline: ALGORITHMIC bytes per launch of each kernel / its HIP-event duration;
+        # the entry for the kernel with the longest duration is reported as `roofline`.
+        #   shape side = 12 B per hull vertex (a box: its 3 half extents), pose = 48 B (fp32 3x4), cull box = 24 B
         a = s.arrays
-        child_v = np.where(a["kind"][a["child_shape"]] == 1, a["vcnt"][a["child_shape"]], 8)
+        child_v = np.where(a["kind"][a["child_shape"]] == 1, a["vcnt"][a["child_shape"]], 1)
         objs, _ = rb.affected_links()
         qch = np.concatenate([np.arange(a["obj_off"][o], a["obj_off"][o] + a["obj_cnt"][o]) for o in objs])
         n_q = float(child_v[qch].mean())
         n_x = float(child_v.mean())       # dominated by the 4096 soup children
-        per_launch_pairs = pair_evals / max(launches, 1)
-        per_launch_contacts = c1["contacts"] / 2.0   # slab of one step holds both launches
-        bytes_per_launch = per_launch_pairs * (12.0 * (n_q + n_x) + 96.0) + per_launch_contacts * (152.0 + 16.0 * rb.K)
-        achieved = bytes_per_launch / (ms["gjk"] * 1e-3) / 1e9 if ms["gjk"] > 0 else 0.0
+        L = max(launches, 1)
+        pairs_l = pair_evals / L
+        gjk_l = (c1["cum_gjk_evals"] - c0["cum_gjk_evals"]) / L
+        epa_l = (c1["cum_epa_evals"] - c0["cum_epa_evals"]) / L
+        hits_l = c1["contacts"] / 2.0     # the slab of one step holds both launches
+        units_l = P * (T - 0.5) * len(qch)  # (unit, query child) wavefronts per launch, mean of the discrete and the cast pass
+        side = lambda nv: 12.0 * nv + 48.0
+        alg = {
+            # every pair evaluation reads the other child's box, shape and pose; each wavefront its query child's
+            "broadphase": pairs_l * (24.0 + side(n_x)) + units_l * (24.0 + side(n_q)) + gjk_l * 16.0,
+            "gjk": gjk_l * (16.0 + side(n_q) + side(n_x)) + hits_l * 32.0 + epa_l * 36.0,
+            "epa": epa_l * (36.0 + side(n_q) + side(n_x) + 32.0),
+            "finish": hits_l * (32.0 + 16.0 + 2 * 7 * 8.0 * 8 + 152.0 + 16.0 * rb.K),   # hit + pair + two link chains (~8 fp64 poses) + record + gradient rows
+        }
+        roof_all = {k: {"algorithmic_bytes_per_launch": alg[k], "ms_per_launch": ms[k],
+                        "achieved_GBs": (alg[k] / (ms[k] * 1e-3) / 1e9 if ms[k] > 0 else 0.0)} for k in alg}
+        dom = max(alg, key=lambda k: ms[k])
+        achieved = roof_all[dom]["achieved_GBs"]
+        kname = {"broadphase": "k_broadphase", "gjk": "k_gjk", "epa": "k_pen+k_epa", "finish": "k_finish"}[dom]
         out = {
             "metric": "signed-distance+Jacobian pair-evals/s (node)",
             "value": pairs_all / dt_max,
@@ -219,15 +233,17 @@ def main():
             "ms_per_sqp_linearization_single_problem_device": lat_dev_ms,
             "api_value": api,
             "kernel_ms_per_launch": ms,
-            "roofline": {"bound": "hbm", "kernel": "k_gjk", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "note": "VALU/cross-lane bound iterative fp32 kernel; bytes are compulsory only (SURVEY 8d)"},
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(dom),
+                         "note": "dominant kernel by HIP-event duration; dependent-latency bound (LDS / L2 round trips of an "
+                                 "iterative fp32 algorithm), far below the HBM roof by nature; bytes are compulsory only (SURVEY 8d)"},
+            "roofline_all": roof_all,
         }
         if not args.no_cpu_baseline:
-            cb = cpu_baseline(s, rb, static_T, d, cc.allowed, dofs[0])
+            cb = cpu_baseline(s, rb, static_T, d, cc.allowed, dofs)
             kind = "reference" if "reference" in cb else "port"
             out["cpu_baseline"] = {"value": cb[kind]["value"], "unit": "pair-evals/s", "cores": 1, "kind": kind,
-                                   "sample": "problem 0, %d of its 100 timesteps (%.1f s of CPU work): discrete LinksVsAll + CastVsAll on one core"
+                                   "sample": "%d (problem, timestep) units of this rank's workload (%.1f s of CPU work): discrete LinksVsAll + CastVsAll per unit on one core"
                                              % (cb[kind]["timesteps"], cb[kind]["seconds"]),
                                    "port_value": cb["port"]["value"]}
         print(json.dumps(out), flush=True)

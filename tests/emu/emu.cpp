@@ -112,6 +112,7 @@ void *emu_create(const ora_scene *sc) {
   }
   for (int i = 0; i < sc->n_verts; ++i) { w->vx.push_back(sc->verts[3 * i]); w->vy.push_back(sc->verts[3 * i + 1]); w->vz.push_back(sc->verts[3 * i + 2]); }
   for (size_t i = 0; i < w->vx.size(); ++i) { F4 p; p.x = w->vx[i]; p.y = w->vy[i]; p.z = w->vz[i]; p.w = 0; w->v4.push_back(p); }
+  { F4 z; z.x = z.y = z.z = z.w = 0; w->v4.resize(w->v4.size() + 64, z); }
   w->vx.resize(w->vx.size() + 64); w->vy.resize(w->vy.size() + 64); w->vz.resize(w->vz.size() + 64);
   for (int i = 0; i < sc->n_children; ++i) { w->child_shape.push_back(sc->child_shape[i]); w->child_T.push_back(xfFrom7(sc->child_T + 7 * i)); }
   for (int i = 0; i < sc->n_objects; ++i) {

@@ -1,0 +1,104 @@
+"""N > 1 path on the CPU: two `gloo` ranks shard a set of multi-start problems (trajopt_amd/multi_gpu.py), each rank
+linearizes its own block -- with the CPU oracle standing in for the GPU engine, this is a test -- and the union must
+equal the single-process result; the scalar reductions of the bench contract (max time, summed units) are checked too.
+There is no data-path collective to test: the ranks never exchange contacts."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from trajopt_amd import multi_gpu  # noqa: E402
+
+N_PROBLEMS, T = 5, 6   # odd on purpose: the blocks are ragged (3 + 2)
+
+
+def _problems():
+    from trajopt_amd import synth
+    s, rb, static_T, d = synth.config_arm_table(seed=0)
+    q0 = rb.q_robot[1:8]
+    trajs = []
+    for g in range(N_PROBLEMS):
+        rng = np.random.default_rng(100 + g)
+        trajs.append(synth.straight_line(q0, q0 + rng.uniform(-0.8, 0.8, size=7), T))
+    return s, rb, static_T, d, np.stack(trajs)
+
+
+def _linearize(s, rb, static_T, d, trajs, lo):
+    from oracle import bindings as B
+    w = B.oracle_world(s)
+    w.set_contact_distance(d)
+    out = []
+    for i, tr in enumerate(trajs):
+        for cast in (False, True):
+            rec, grads = w.linearize(rb, static_T, tr, cast=cast)
+            for r, g in zip(rec, grads):
+                out.append((lo + i, int(cast), int(r["t"]), int(r["c"]["objA"]), int(r["c"]["childA"]), int(r["c"]["objB"]),
+                            int(r["c"]["childB"]), float(r["c"]["dist"]), g.tobytes()))
+    pe = w.counter(0)
+    w.close()
+    return out, pe
+
+
+def _rank_main(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s, rb, static_T, d, trajs = _problems()
+        lo, hi = multi_gpu.partition(N_PROBLEMS, world, rank)
+        mine, pe = _linearize(s, rb, static_T, d, trajs[lo:hi], lo)
+        dist.barrier()
+        tmax, usum = multi_gpu.reduce_measurement(1.0 + rank, pe, dist)
+        counts = multi_gpu.gather_counts(len(mine), dist)
+        q.put((rank, lo, hi, mine, pe, tmax, usum, counts.tolist()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_partition_covers_every_problem_once():
+    for n in (0, 1, 5, 8, 17):
+        for world in (1, 2, 3, 8):
+            blocks = [multi_gpu.partition(n, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        multi_gpu.partition(4, 2, 2)
+
+
+def test_single_process_reduction_is_identity():
+    assert multi_gpu.reduce_measurement(0.25, 1000) == (0.25, 1000.0)
+    assert multi_gpu.gather_counts(7).tolist() == [7]
+
+
+@pytest.mark.timeout(300)
+def test_two_gloo_ranks_shard_the_problems():
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=240) for _ in procs])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    s, rb, static_T, d, trajs = _problems()
+    ref, pe_ref = _linearize(s, rb, static_T, d, trajs, 0)
+    assert [(g[1], g[2]) for g in got] == [(0, 3), (3, 5)]
+    union = got[0][3] + got[1][3]
+    assert sorted(union) == sorted(ref) and len(ref) > 0          # same contacts, distances and gradient rows, bit for bit
+    assert got[0][4] + got[1][4] == pe_ref                          # pair evaluations add up: nothing done twice or skipped
+    for g in got:
+        assert g[5] == 2.0 and g[6] == float(pe_ref)                # max over ranks of the time, sum of the units
+        assert g[7] == [len(got[0][3]), len(got[1][3])]

@@ -141,7 +141,7 @@ struct tohc_engine {
   bool last_robot_mode = true, last_want_jac = false;
   size_t fetched_n = 0;
   int gjk_group = 1;  // lanes per pair in k_gjk: 1 (default), 16 or 64 (TOHC_GJK_GROUP)
-  int epa_block = 16;  // threads per k_epa block (TOHC_EPA_BLOCK = 16 or 64)
+  int epa_block = 64;  // threads per k_epa block (TOHC_EPA_BLOCK = 16 or 64)
   int pretest = 1;   // TOHC_PRETEST=0 turns the separating-axis pre-test off (A/B measurements)
   tohc_engine() { memset(&counters, 0, sizeof counters); }
 };
@@ -212,7 +212,7 @@ int tohc_create(tohc_engine **out, int device) {
       delete e;
       return TOHC_E_HIP;
     }
-  if (const char *eb = getenv("TOHC_EPA_BLOCK")) e->epa_block = atoi(eb) == 64 ? 64 : 16;
+  if (const char *eb = getenv("TOHC_EPA_BLOCK")) e->epa_block = atoi(eb) == 16 ? 16 : 64;
   if (const char *hs = getenv("TOHC_HOST_SORT")) e->host_sort = atoi(hs) != 0;
   e->gjk_group = e->group == 64 ? 64 : 1;
   if (const char *gg = getenv("TOHC_GJK_GROUP")) { int v = atoi(gg); if (v == 1 || v == 16 || v == 64) e->gjk_group = v; }

@@ -19,7 +19,7 @@
 namespace tohc {
 
 struct V3 { float x, y, z; };
-struct F4 { float x, y, z, w; };  // one hull vertex as a 16-byte record (lane-per-pair kernels read vertices from memory)
+struct alignas(16) F4 { float x, y, z, w; };  // one hull vertex as a 16-byte record (lane-per-pair kernels read vertices from memory)
 struct M3 { V3 r[3]; };
 struct Xf { M3 b; V3 o; };
 

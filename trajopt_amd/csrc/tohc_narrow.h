@@ -161,14 +161,22 @@ TOHC_DEV V3 hullMaxDot(const Cvx<G> &c, V3 d) {
   return mk(Grp<G>::bcast(sx, src), Grp<G>::bcast(sy, src), Grp<G>::bcast(sz, src));
 }
 
+// The scan reads 8 vertices ahead of the compare chain: with one load per step the loop would be a chain of L2 round
+// trips (~300 cycles each), which is what a lane-per-pair support query costs otherwise.  The vertex table is padded
+// with 64 records, so reading up to 7 past a hull's end stays in bounds; those lanes of the compare are masked.
 template <>
 TOHC_DEV V3 hullMaxDot<1>(const Cvx<1> &c, V3 d) {
   float best = -INFINITY;
   V3 bv = mk(0, 0, 0);
-  for (int i = 0; i < c.n; ++i) {
-    const F4 p = c.v[i];
-    float dt = p.x * d.x + p.y * d.y + p.z * d.z;
-    if (dt > best) { best = dt; bv = mk(p.x, p.y, p.z); }
+  for (int i0 = 0; i0 < c.n; i0 += 8) {
+    F4 p[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k] = c.v[i0 + k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float dt = p[k].x * d.x + p[k].y * d.y + p[k].z * d.z;
+      if (i0 + k < c.n && dt > best) { best = dt; bv = mk(p[k].x, p[k].y, p[k].z); }
+    }
   }
   if (!(best > -INFINITY) && c.n > 0) { const F4 p = c.v[0]; bv = mk(p.x, p.y, p.z); }  // all-NaN dots: index 0, like the scan
   return bv;
@@ -595,20 +603,21 @@ TOHC_DEV void gjkMain(const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &
 #define TOHC_EPA_MAX_FACES 128
 #define TOHC_NIL 255
 
-struct EpaMem {
+// One record per access: a face is read as (normal, distance) = one 16-byte load, its three vertex ids + pass mark
+// = one 4-byte load, its neighbours and their edge numbers = two 4-byte loads -- EPA is a chain of dependent LDS round
+// trips, so what counts is how few of them a step needs, not how many bytes.  Which faces are on the hull / free is
+// kept in two 128-bit masks in registers (Epa), not in linked lists: the list order matters to the reference only in
+// findbest's tie rule, which the arrival stamp reproduces.
+struct alignas(16) EpaMem {
   // support vertices: 0..3 = GJK2's m_store, 4..67 = EPA's m_sv_store
-  float svd[4 + TOHC_EPA_MAX_VERTICES][3];
-  float svw[4 + TOHC_EPA_MAX_VERTICES][3];
-  float fn[TOHC_EPA_MAX_FACES][3];
-  float fd[TOHC_EPA_MAX_FACES];
-  uint8_t fc[TOHC_EPA_MAX_FACES][3];
-  uint8_t ff[TOHC_EPA_MAX_FACES][3];
-  uint8_t fe[TOHC_EPA_MAX_FACES][3];
-  uint8_t fl[TOHC_EPA_MAX_FACES][2];
-  uint8_t fpass[TOHC_EPA_MAX_FACES];
-  uint8_t fhull[TOHC_EPA_MAX_FACES];    // 1 while the face is on the hull list
-  uint16_t fstamp[TOHC_EPA_MAX_FACES];  // order of arrival on the hull list (the list is newest-first)
-  uint8_t stF[TOHC_EPA_MAX_FACES], stE[TOHC_EPA_MAX_FACES], stS[TOHC_EPA_MAX_FACES];  // expand() stack
+  float svd[4 + TOHC_EPA_MAX_VERTICES][4];
+  float svw[4 + TOHC_EPA_MAX_VERTICES][4];
+  float fnd[TOHC_EPA_MAX_FACES][4];      // n.x n.y n.z d
+  uint32_t fcp[TOHC_EPA_MAX_FACES];      // bytes: c[0] c[1] c[2] pass
+  uint32_t ff[TOHC_EPA_MAX_FACES];       // bytes: f[0] f[1] f[2] -
+  uint32_t fe[TOHC_EPA_MAX_FACES];       // bytes: e[0] e[1] e[2] -
+  uint16_t fstamp[TOHC_EPA_MAX_FACES];   // order of arrival on the hull (the reference's hull list is newest-first)
+  uint16_t stk[TOHC_EPA_MAX_FACES];      // expand() stack: face | edge << 8 | stage << 10
   // GJK2 simplices
   uint8_t sc[2][4];
   float sp[2][4];
@@ -930,39 +939,28 @@ struct Epa {
   V3 normal;
   float depth;
   unsigned nextsv;
-  unsigned hullRoot, hullCount, stockRoot, stockCount;
+  unsigned long long hullLo, hullHi, freeLo, freeHi;   // faces 0..63 / 64..127 on the hull, in the stock
+  unsigned hullCount;
   unsigned stamp;
   EpaProf prof;
   // horizon
   unsigned hcf, hff, hnf;
 
   TOHC_DEV V3 svW(unsigned sv) const { return ld3(m->svw[sv]); }
+  static TOHC_DEV unsigned byteOf(uint32_t w, unsigned k) { return (w >> (8 * k)) & 255u; }
   TOHC_DEV void bind(unsigned fa, unsigned ea, unsigned fb, unsigned eb) {
-    m->fe[fa][ea] = (uint8_t)eb; m->ff[fa][ea] = (uint8_t)fb;
-    m->fe[fb][eb] = (uint8_t)ea; m->ff[fb][eb] = (uint8_t)fa;
+    ((uint8_t *)&m->fe[fa])[ea] = (uint8_t)eb; ((uint8_t *)&m->ff[fa])[ea] = (uint8_t)fb;
+    ((uint8_t *)&m->fe[fb])[eb] = (uint8_t)ea; ((uint8_t *)&m->ff[fb])[eb] = (uint8_t)fa;
   }
-  TOHC_DEV void append(unsigned &root, unsigned &count, unsigned f) {
-    m->fl[f][0] = TOHC_NIL;
-    m->fl[f][1] = (uint8_t)root;
-    if (root != TOHC_NIL) m->fl[root][0] = (uint8_t)f;
-    root = f;
-    ++count;
-  }
-  TOHC_DEV void removeF(unsigned &root, unsigned &count, unsigned f) {
-    unsigned l1 = m->fl[f][1], l0 = m->fl[f][0];
-    if (l1 != TOHC_NIL) m->fl[l1][0] = (uint8_t)l0;
-    if (l0 != TOHC_NIL) m->fl[l0][1] = (uint8_t)l1;
-    if (f == root) root = l1;
-    --count;
-  }
-  TOHC_DEV void hullAppend(unsigned f) {
-    append(hullRoot, hullCount, f);
-    m->fhull[f] = 1;
+  TOHC_DEV bool onHull(unsigned f) const { return (((f < 64 ? hullLo : hullHi) >> (f & 63)) & 1ull) != 0; }
+  TOHC_DEV void hullAppend(unsigned f) {   // append(m_hull, face)
+    if (f < 64) hullLo |= 1ull << f; else hullHi |= 1ull << (f - 64);
+    ++hullCount;
     m->fstamp[f] = (uint16_t)(++stamp);
   }
-  TOHC_DEV void hullRemove(unsigned f) {
-    removeF(hullRoot, hullCount, f);
-    m->fhull[f] = 0;
+  TOHC_DEV void hullToStock(unsigned f) {  // remove(m_hull, face); append(m_stock, face)
+    if (f < 64) { hullLo &= ~(1ull << f); freeLo |= 1ull << f; } else { hullHi &= ~(1ull << (f - 64)); freeHi |= 1ull << (f - 64); }
+    --hullCount;
   }
   TOHC_DEV void init() {  // [epa:583-593]
     status = E_FAILED;
@@ -970,14 +968,9 @@ struct Epa {
     depth = 0;
     nextsv = 0;
     stamp = 0;
-    hullRoot = TOHC_NIL; hullCount = 0;
-    // the reference pushes faces 127..0 onto the stock list one by one; the result is the list 0,1,...,127
-    for (unsigned f = (unsigned)Grp<G>::lane(); f < TOHC_EPA_MAX_FACES; f += G) {
-      m->fl[f][0] = (uint8_t)(f == 0 ? TOHC_NIL : f - 1);
-      m->fl[f][1] = (uint8_t)(f == TOHC_EPA_MAX_FACES - 1 ? TOHC_NIL : f + 1);
-      m->fhull[f] = 0;
-    }
-    stockRoot = 0; stockCount = TOHC_EPA_MAX_FACES;
+    hullLo = hullHi = 0;
+    hullCount = 0;
+    freeLo = freeHi = ~0ull;
   }
   TOHC_DEV bool getedgedist(V3 fnrm, V3 a, V3 b, float &dist) {  // [epa:698-733]
     V3 ba = b - a;
@@ -998,13 +991,15 @@ struct Epa {
     }
     return false;
   }
-  TOHC_DEV unsigned newface(unsigned a, unsigned b, unsigned c, bool forced) {  // [epa:734-778]
-    if (stockRoot != TOHC_NIL) {
-      unsigned face = stockRoot;
-      removeF(stockRoot, stockCount, face);
+  // [epa:734-778].  The reference takes the stock list's root; WHICH free slot a face gets is invisible in the results
+  // (faces are told apart by geometry, adjacency and arrival stamp only), so the lowest free slot is taken.
+  TOHC_DEV unsigned newface(unsigned a, unsigned b, unsigned c, bool forced) {
+    if ((freeLo | freeHi) != 0) {
+      unsigned face;
+      if (freeLo) { face = (unsigned)__builtin_ctzll(freeLo); freeLo &= freeLo - 1; }
+      else { face = 64u + (unsigned)__builtin_ctzll(freeHi); freeHi &= freeHi - 1; }
       hullAppend(face);
-      m->fpass[face] = 0;
-      m->fc[face][0] = (uint8_t)a; m->fc[face][1] = (uint8_t)b; m->fc[face][2] = (uint8_t)c;
+      m->fcp[face] = a | (b << 8) | (c << 16);   // pass = 0
       V3 aw = svW(a), bw = svW(b), cw = svW(c);
       V3 n = cross(bw - aw, cw - aw);
       float l = len(n);
@@ -1013,16 +1008,14 @@ struct Epa {
         float d;
         if (!(getedgedist(n, aw, bw, d) || getedgedist(n, bw, cw, d) || getedgedist(n, cw, aw, d))) d = dot(aw, n) / l;
         n = vdiv(n, l);
-        st3(m->fn[face], n);
-        m->fd[face] = d;
+        float *o = m->fnd[face];
+        o[0] = n.x; o[1] = n.y; o[2] = n.z; o[3] = d;
         if (forced || (d >= -0.00001f)) return face;
         else status = E_NONCONVEX;
       } else {
-        st3(m->fn[face], n);
         status = E_DEGENERATED;
       }
-      hullRemove(face);
-      append(stockRoot, stockCount, face);
+      hullToStock(face);
       return TOHC_NIL;
     }
     status = E_OUTOFFACES;
@@ -1030,37 +1023,42 @@ struct Epa {
   }
   // findbest [epa:779-793] walks the hull list from its root (newest face first) and keeps the first strict
   // minimum of d*d.  Same result without the pointer chase: every lane looks at its share of the face array, and
-  // among equal minima the newest face (largest stamp) wins.
+  // among equal minima the newest face (largest stamp) wins.  (A NaN distance never wins; the reference would return
+  // the list root if the ROOT's were NaN -- finite shapes cannot produce one.)
   TOHC_DEV unsigned findbest() {
-    const float rootD = m->fd[hullRoot];
     float best = INFINITY;
     int bkey = -1;   // (stamp << 8) | face; larger = earlier in the list
     for (unsigned f = (unsigned)Grp<G>::lane(); f < TOHC_EPA_MAX_FACES; f += G) {
-      if (!m->fhull[f]) continue;
-      const float sqd = m->fd[f] * m->fd[f];
+      if (!onHull(f)) continue;
+      const float d = m->fnd[f][3];
+      const float sqd = d * d;
       const int key = ((int)m->fstamp[f] << 8) | (int)f;
       if (sqd < best || (sqd == best && key > bkey)) { best = sqd; bkey = key; }
     }
     // group-wide arg-min with the same tie rule: arg-max of (-d*d, key); a lane that saw nothing holds (-inf, -1)
     float nb = -best;
     Grp<G>::argmax_hi(nb, bkey);
-    if (!(rootD * rootD == rootD * rootD) || bkey < 0) return hullRoot;  // NaN at the root: no '<' ever succeeds
+    if (bkey < 0) return hullLo ? (unsigned)__builtin_ctzll(hullLo) : 64u + (unsigned)__builtin_ctzll(hullHi);
     return (unsigned)(bkey & 255);
   }
   // expand [epa:794-827] on an explicit stack (stage 0: entry, 1: first child returned, 2: second child returned)
   TOHC_DEV bool expand(unsigned pass, unsigned w, unsigned f0, unsigned e0) {
-    int sp = 0;
+    int sp = 1;
     bool ret = false;
-    m->stF[0] = (uint8_t)f0; m->stE[0] = (uint8_t)e0; m->stS[0] = 0;
-    sp = 1;
+    m->stk[0] = (uint16_t)(f0 | (e0 << 8));
     const V3 ww = svW(w);
     while (sp > 0) {
-      const unsigned f = m->stF[sp - 1], e = m->stE[sp - 1], stage = m->stS[sp - 1];
+      const unsigned ent = m->stk[sp - 1];
+      const unsigned f = ent & 255u, e = (ent >> 8) & 3u, stage = ent >> 10;
       const unsigned e1 = (e + 1) % 3, e2 = (e + 2) % 3;
       if (stage == 0) {
-        if (m->fpass[f] != pass) {
-          if ((dot(ld3(m->fn[f]), ww) - m->fd[f]) < -0.00001f) {
-            unsigned nf = newface(m->fc[f][e1], m->fc[f][e], w, false);
+        // everything this visit can need, issued together: one LDS round trip
+        const uint32_t cp = m->fcp[f], fw = m->ff[f], ew = m->fe[f];
+        const float *nd = m->fnd[f];
+        const float nx = nd[0], ny = nd[1], nz = nd[2], fd = nd[3];
+        if ((cp >> 24) != pass) {
+          if ((dot(mk(nx, ny, nz), ww) - fd) < -0.00001f) {
+            unsigned nf = newface(byteOf(cp, e1), byteOf(cp, e), w, false);
             if (nf != TOHC_NIL) {
               bind(nf, 0, f, e);
               if (hcf != TOHC_NIL) bind(hcf, 1, nf, 2); else hff = nf;
@@ -1071,10 +1069,10 @@ struct Epa {
               ret = false;
             --sp;
           } else {
-            m->fpass[f] = (uint8_t)pass;
-            m->stS[sp - 1] = 1;
+            ((uint8_t *)&m->fcp[f])[3] = (uint8_t)pass;
+            m->stk[sp - 1] = (uint16_t)(f | (e << 8) | (1u << 10));
             if (sp >= TOHC_EPA_MAX_FACES) { ret = false; --sp; continue; }  // cannot happen: depth <= hull faces
-            m->stF[sp] = m->ff[f][e1]; m->stE[sp] = m->fe[f][e1]; m->stS[sp] = 0;
+            m->stk[sp] = (uint16_t)(byteOf(fw, e1) | (byteOf(ew, e1) << 8));
             ++sp;
           }
         } else {
@@ -1083,8 +1081,9 @@ struct Epa {
         }
       } else if (stage == 1) {
         if (ret) {
-          m->stS[sp - 1] = 2;
-          m->stF[sp] = m->ff[f][e2]; m->stE[sp] = m->fe[f][e2]; m->stS[sp] = 0;
+          const uint32_t fw = m->ff[f], ew = m->fe[f];
+          m->stk[sp - 1] = (uint16_t)(f | (e << 8) | (2u << 10));
+          m->stk[sp] = (uint16_t)(byteOf(fw, e2) | (byteOf(ew, e2) << 8));
           ++sp;
         } else {
           ret = false;
@@ -1092,8 +1091,7 @@ struct Epa {
         }
       } else {
         if (ret) {
-          hullRemove(f);
-          append(stockRoot, stockCount, f);
+          hullToStock(f);
           ret = true;
         } else
           ret = false;
@@ -1109,11 +1107,7 @@ struct Epa {
     const bool enclosed = (g.rk(s) > 1) && g.encloseOrigin();
     TOHC_PROF_ACC(prof, 4, tenc);
     if (enclosed) {
-      while (hullRoot != TOHC_NIL) {
-        unsigned f = hullRoot;
-        hullRemove(f);
-        append(stockRoot, stockCount, f);
-      }
+      // (the reference first returns a previous run's hull to the stock; here every evaluation starts from init())
       status = E_VALID;
       nextsv = 0;
       unsigned c0 = m->sc[s][0], c1 = m->sc[s][1], c2 = m->sc[s][2], c3 = m->sc[s][3];
@@ -1130,9 +1124,9 @@ struct Epa {
       TOHC_PROF_ACC(prof, 5, tnf);
       if (hullCount == 4) {
         unsigned best = findbest();
-        V3 outerN = ld3(m->fn[best]);
-        float outerD = m->fd[best];
-        unsigned oc0 = m->fc[best][0], oc1 = m->fc[best][1], oc2 = m->fc[best][2];
+        V3 outerN = ld3(m->fnd[best]);
+        float outerD = m->fnd[best][3];
+        uint32_t ocp = m->fcp[best];
         unsigned pass = 0, iterations = 0;
         bind(t0, 0, t1, 0);
         bind(t0, 1, t2, 0);
@@ -1146,32 +1140,36 @@ struct Epa {
             hcf = TOHC_NIL; hff = TOHC_NIL; hnf = 0;
             unsigned w = 4 + nextsv++;
             bool valid = true;
-            m->fpass[best] = (uint8_t)(++pass);
-            V3 bn = ld3(m->fn[best]);
+            ((uint8_t *)&m->fcp[best])[3] = (uint8_t)(++pass);
+            const uint32_t bfw = m->ff[best], bew = m->fe[best];
+            V3 bn = ld3(m->fnd[best]);
+            const float bd = m->fnd[best][3];
             TOHC_PROF_T0(ts);
             g.support(bn, w);
             TOHC_PROF_ACC(prof, 1, ts);
-            float wdist = dot(bn, svW(w)) - m->fd[best];
+            float wdist = dot(bn, svW(w)) - bd;
             if (wdist > 0.0001f) {
               TOHC_PROF_T0(te);
-              for (unsigned j = 0; (j < 3) && valid; ++j) valid &= expand(pass, w, m->ff[best][j], m->fe[best][j]);
+              // best's own adjacency is not rewritten while its neighbours are expanded (binds touch the new faces
+              // and the faces beyond the horizon), so the words read above stay current
+              for (unsigned j = 0; (j < 3) && valid; ++j) valid &= expand(pass, w, byteOf(bfw, j), byteOf(bew, j));
               TOHC_PROF_ACC(prof, 2, te);
               if (valid && (hnf >= 3)) {
                 bind(hcf, 1, hff, 2);
-                hullRemove(best);
-                append(stockRoot, stockCount, best);
+                hullToStock(best);
                 TOHC_PROF_T0(tf);
                 best = findbest();
                 TOHC_PROF_ACC(prof, 3, tf);
-                outerN = ld3(m->fn[best]);
-                outerD = m->fd[best];
-                oc0 = m->fc[best][0]; oc1 = m->fc[best][1]; oc2 = m->fc[best][2];
+                outerN = ld3(m->fnd[best]);
+                outerD = m->fnd[best][3];
+                ocp = m->fcp[best];
               } else { status = E_INVALIDHULL; break; }
             } else { status = E_ACCURACY; break; }
           } else { status = E_OUTOFVERTICES; break; }
         }
         TOHC_STAT(emuStats().epa_calls++; emuStats().epa_iters += iterations; emuStats().epa_faces += hullCount;
                   emuStats().hist_epa[iterations < 71 ? iterations : 71]++; emuStats().status[status]++;)
+        const unsigned oc0 = byteOf(ocp, 0), oc1 = byteOf(ocp, 1), oc2 = byteOf(ocp, 2);
         V3 projection = outerN * outerD;
         normal = outerN;
         depth = outerD;
