@@ -84,6 +84,7 @@ struct tohc_engine {
   double base_T[7], rot_axis[3];
   DBuf<int> d_parent, d_jtype, d_dof, d_dof_col, d_link_dyn, d_obj_jaclink, d_link_obj, d_chain_off, d_chain;
   std::vector<int> h_chain_off, h_chain;
+  bool shared_columns = false;
   DBuf<double> d_T_origin, d_axis, d_mult, d_offs, d_q_robot;
   // dynamic maps: robot mode and all-objects ("poses") mode
   std::vector<int> h_obj_dynR, h_child_dynR, h_dyn_childrenR, h_qchildrenR;
@@ -498,11 +499,19 @@ int tohc_upload_robot(tohc_engine *e, int n_links, const int32_t *parent, const 
     if (e->h_child_dynR[c] < 0) e->h_stat_childrenR.push_back(c);
   // ancestors of each link, root first (k_fk composes every chain in that order)
   e->h_chain_off.assign(n_links + 1, 0); e->h_chain.clear();
+  e->shared_columns = false;
   for (int i = 0; i < n_links; ++i) {
     std::vector<int> up;
     for (int j = i; j >= 0; j = parent[j]) up.push_back(j);
     for (auto it = up.rbegin(); it != up.rend(); ++it) e->h_chain.push_back(*it);
     e->h_chain_off[i + 1] = (int)e->h_chain.size();
+    // two moving joints of one chain on the same optimisation column (mimic joints): their Jacobian columns add
+    // BEFORE the product with the normal, which the lane-per-joint epilogue of k_finish does not do
+    for (size_t a = (size_t)e->h_chain_off[i]; a < e->h_chain.size(); ++a)
+      for (size_t b = a + 1; b < e->h_chain.size(); ++b) {
+        const int ja = e->h_chain[a], jb = e->h_chain[b];
+        if (e->h_jtype[ja] != TOHC_J_FIXED && e->h_jtype[jb] != TOHC_J_FIXED && e->h_dof_col[ja] >= 0 && e->h_dof_col[ja] == e->h_dof_col[jb]) e->shared_columns = true;
+      }
   }
   hipStream_t s = e->stream;
   HIPCHK(upload(e->d_parent, e->h_parent, s)); HIPCHK(upload(e->d_jtype, e->h_jtype, s)); HIPCHK(upload(e->d_dof, e->h_dof, s));
@@ -583,6 +592,7 @@ static DevRobot devRobot(tohc_engine *e) {
   r.parent = e->d_parent.p; r.jtype = e->d_jtype.p; r.dof = e->d_dof.p; r.dof_col = e->d_dof_col.p; r.link_dyn = e->d_link_dyn.p;
   r.T_origin = e->d_T_origin.p; r.axis = e->d_axis.p; r.mult = e->d_mult.p; r.offs = e->d_offs.p; r.q_robot = e->d_q_robot.p;
   r.obj_jaclink = e->d_obj_jaclink.p; r.link_obj = e->d_link_obj.p; r.chain_off = e->d_chain_off.p; r.chain = e->d_chain.p;
+  r.fast_jac = (!e->shared_columns && e->K <= TOHC_FAST_JAC_MAXK) ? 1 : 0;
   memcpy(r.base_T, e->base_T, sizeof r.base_T);
   memcpy(r.rot_axis, e->rot_axis, sizeof r.rot_axis);
   return r;

@@ -56,8 +56,10 @@ struct DynMap {          // which objects / children move per set (robot links, 
   const float *cl_soa;       // [6][n_cl_pad] box of each cluster of 64 consecutive table entries
   int n_cl, n_cl_pad;
 };
+#define TOHC_FAST_JAC_MAXK 64
 struct DevRobot {
   int n_links, K, n_joint_inds, affine;
+  int fast_jac;   // 1: no chain has two joints on one column and K <= TOHC_FAST_JAC_MAXK (k_finish's lane-per-joint epilogue applies)
   const int *parent, *jtype, *dof, *dof_col, *link_dyn, *link_obj;
   const int *chain_off, *chain;                          // ancestors of each link, root first, the link itself last
   const double *T_origin, *axis, *mult, *offs, *q_robot;
@@ -712,10 +714,68 @@ __device__ __forceinline__ double linearizeAt(const NarrowArgs &a, int set, int 
   return dist - gq;
 }
 
+// The same linearization with one lane per JOINT of the link's chain instead of one lane per column: a lane loads its
+// joint's record and pose (independent loads, one round trip for the whole chain instead of a pointer chase per
+// column) and, if the joint moves an optimisation column, leaves n . J[column] in the group's LDS row.  Values equal
+// linearizeAt's: with at most one joint per column (DevRobot.fast_jac) a column's J is 0 + mult*col, exactly.
+// row: [2][TOHC_FAST_JAC_MAXK] doubles of the group (A's then B's contributions).
+template <int G>
+__device__ __forceinline__ void jacRow(const DevRobot &rb, const double *linkQT, int link, D3 n, D3 p, double *row) {
+  const int gl = Grp<G>::lane();
+  const int c0 = rb.chain_off[link], c1 = rb.chain_off[link + 1];
+  for (int c = c0 + gl; c < c1; c += G) {
+    const int i = rb.chain[c];
+    const int k = rb.dof_col[i];
+    if (rb.jtype[i] == TOHC_J_FIXED || k < 0 || k >= rb.n_joint_inds) continue;
+    Dxf t = dxfFrom7(linkQT + 7 * i);
+    D3 z = qrot(t.q, mkd(rb.axis[3 * i], rb.axis[3 * i + 1], rb.axis[3 * i + 2]));
+    D3 col = rb.jtype[i] == TOHC_J_REVOLUTE ? cross(z, p - t.t) : z;
+    D3 J = mkd(0, 0, 0);
+    J.x += rb.mult[i] * col.x; J.y += rb.mult[i] * col.y; J.z += rb.mult[i] * col.z;
+    row[k] = n.x * J.x + n.y * J.y + n.z * J.z;
+  }
+}
+template <int G>
+__device__ __forceinline__ double linearizeFast(const NarrowArgs &a, int set, int la, int lb, D3 n, D3 ptA, D3 ptB, double dist, double *gradOut,
+                                                double *row) {
+  const DevRobot &rb = a.rb;
+  const int gl = Grp<G>::lane();
+  const double *linkQT = a.linkQT + (size_t)set * rb.n_links * 7;
+  const double *q = a.dofs + (size_t)set * rb.K;
+  double *rowA = row, *rowB = row + TOHC_FAST_JAC_MAXK;
+  for (int k = gl; k < rb.K; k += G) {
+    double va = 0, vb = 0;
+    if (k >= rb.n_joint_inds) {  // affine columns: no chain involved
+      if (la >= 0) { D3 J = jacColumn(rb, linkQT, q, la, ptA, k); va = n.x * J.x + n.y * J.y + n.z * J.z; }
+      if (lb >= 0) { D3 J = jacColumn(rb, linkQT, q, lb, ptB, k); vb = n.x * J.x + n.y * J.y + n.z * J.z; }
+    }
+    rowA[k] = va; rowB[k] = vb;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the group's lanes share one wavefront: LDS ops are in order
+  if (la >= 0) jacRow<G>(rb, linkQT, la, n, ptA, rowA);
+  if (lb >= 0) jacRow<G>(rb, linkQT, lb, n, ptB, rowB);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (int k = gl; k < rb.K; k += G) {
+    double g = 0;
+    if (la >= 0) g += 1.0 * rowA[k];
+    if (lb >= 0) g += -1.0 * rowB[k];
+    gradOut[k] = g;
+    rowA[k] = g;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  double gq = 0;
+  for (int k = 0; k < rb.K; ++k) gq += rowA[k] * q[k];   // column order, like linearizeAt
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  return dist - gq;
+}
+
 // k_finish: btBridgedManifoldResult::addContactPoint (btCollisionWorld.cpp:1068-1086), CastCollisionCollector
 // (bullet_collision_checker.cpp:894-972), record + gradient rows.
 template <int G>
 __global__ void __launch_bounds__(256) k_finish(NarrowArgs a) {
+  __shared__ double s_rows[256 / G][2 * TOHC_FAST_JAC_MAXK];
+  double *row = s_rows[threadIdx.x / G];
+  const bool fast = a.rb.fast_jac != 0;
   const int groupsPerBlock = 256 / G;
   const unsigned int gid = blockIdx.x * groupsPerBlock + threadIdx.x / G;
   const unsigned int ngroups = gridDim.x * groupsPerBlock;
@@ -767,9 +827,12 @@ __global__ void __launch_bounds__(256) k_finish(NarrowArgs a) {
       const int la = a.rb.obj_jaclink[idA], lb = a.rb.obj_jaclink[idB];
       D3 n = mkd(nrm.x, nrm.y, nrm.z), pA = mkd(ptA.x, ptA.y, ptA.z), pB = mkd(ptB.x, ptB.y, ptB.z), pB1 = mkd(ptB1.x, ptB1.y, ptB1.z);
       double *g = a.grads + (size_t)slot * 2 * a.rb.K;
-      c0 = linearizeAt<G>(a, c.set0, la, lb, n, pA, pB, (double)h.distance, g);
+      c0 = fast ? linearizeFast<G>(a, c.set0, la, lb, n, pA, pB, (double)h.distance, g, row)
+                : linearizeAt<G>(a, c.set0, la, lb, n, pA, pB, (double)h.distance, g);
       if (a.cp.cast) {
-        c1 = linearizeAt<G>(a, c.set1, la, lb, n, pA, (cctype == TOHC_CC_BETWEEN) ? pB1 : pB, (double)h.distance, g + a.rb.K);
+        const D3 pBc = (cctype == TOHC_CC_BETWEEN) ? pB1 : pB;
+        c1 = fast ? linearizeFast<G>(a, c.set1, la, lb, n, pA, pBc, (double)h.distance, g + a.rb.K, row)
+                  : linearizeAt<G>(a, c.set1, la, lb, n, pA, pBc, (double)h.distance, g + a.rb.K);
       } else {
         for (int k = gl; k < a.rb.K; k += G) g[a.rb.K + k] = 0;
       }
