@@ -111,8 +111,9 @@ struct tohc_engine {
     DBuf<PenRec> penq;
     DBuf<HitRec> hits;
   };
-  Lane lane[2];
-  int n_lanes = 2;                   // TOHC_STREAMS=1: everything on one lane
+  Lane lane[4];
+  int n_lanes = 4;                   // TOHC_STREAMS=1..4
+  int chunks = 1;                    // a large enqueue is cut into this many unit ranges, one per lane (TOHC_CHUNKS)
   hipEvent_t ev_fk = nullptr;        // the FK of the staged DOF vectors has finished (main stream)
   bool fk_done = false;
   DBuf<unsigned long long> d_dbg;   // TOHC_EPA_PROF builds only
@@ -206,7 +207,8 @@ int tohc_create(tohc_engine **out, int device) {
   const char *g = getenv("TOHC_GROUP");
   if (g && atoi(g) == 64) e->group = 64;
   if (const char *pt = getenv("TOHC_PRETEST")) e->pretest = atoi(pt) != 0;
-  if (const char *ns = getenv("TOHC_STREAMS")) e->n_lanes = atoi(ns) == 1 ? 1 : 2;
+  if (const char *ns = getenv("TOHC_STREAMS")) e->n_lanes = std::min(std::max(atoi(ns), 1), 4);
+  if (const char *nc = getenv("TOHC_CHUNKS")) e->chunks = std::min(std::max(atoi(nc), 1), 4);
   if (hipEventCreateWithFlags(&e->ev_fk, hipEventDisableTiming) != hipSuccess) { delete e; return TOHC_E_HIP; }
   for (auto &ln : e->lane)
     if (hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ln.done, hipEventDisableTiming) != hipSuccess) {
@@ -701,7 +703,9 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
   hipEvent_t *ev = &e->events[(size_t)slot * NEV];
   HIPCHK(hipStreamWaitEvent(s, e->ev_fk, 0));   // pose tables of this call (FK / k_dyn_children on the main stream)
   // a new slab starts only after everything that wrote the old one
-  if (!append && prev && prev != &ln) HIPCHK(hipStreamWaitEvent(s, prev->done, 0));
+  if (!append && prev)
+    for (auto &other : e->lane)
+      if (&other != &ln) HIPCHK(hipStreamWaitEvent(s, other.done, 0));
   HIPCHK(hipMemsetAsync(e->d_cnt.p + slot, 0, sizeof(Counters), s));
   if (!append) HIPCHK(hipMemsetAsync(e->d_nrec.p, 0, sizeof(unsigned int), s));
   cp.seg_cap = (unsigned int)(e->max_pairs / TOHC_NSHARD); cp.max_records = (unsigned int)e->max_records;
@@ -770,7 +774,6 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
   e->last_robot_mode = robotMode;
   e->last_want_jac = robotMode && cp.want_jac;
   e->last_T = cp.T;
-  e->last_sets = (int64_t)cp.T * ((cp.n_cast_sets + std::max(cp.T - cp.gap, 1) - 1) / std::max(cp.T - cp.gap, 1));
   return TOHC_OK;
 }
 
@@ -831,8 +834,26 @@ static int enqueueRobot(tohc_engine *e, int gap, int cast, int filter_mask, int 
   CallParams cp;
   memset(&cp, 0, sizeof cp);
   cp.T = T; cp.gap = cast ? gap : 0; cp.cast = cast; cp.filter_mask = filter_mask; cp.want_jac = want_jac; cp.d = e->d; cp.breaking = e->breaking;
-  cp.n_cast_sets = cast ? B * std::max(T - gap, 0) : B * T;
-  return launchNarrow(e, dm, e->d_qchildrenR.p, e->h_qchildrenR, cp, true, slot, append != 0);
+  const int units = cast ? B * std::max(T - gap, 0) : B * T;
+  e->last_sets = (int64_t)n_sets;
+  // large enqueues are cut into unit ranges that run on different lanes: the kernels are latency bound, so
+  // independent ranges overlap almost perfectly
+  const int C = units >= 256 * e->chunks ? e->chunks : 1;
+  for (int c = 0; c < C; ++c) {
+    if (c > 0) {
+      rc = nextSlot(e, &slot);
+      if (rc != TOHC_OK) return rc;
+      hipStream_t ls = e->lane[slot % e->n_lanes].stream;
+      hipEvent_t *evc = &e->events[(size_t)slot * NEV];
+      HIPCHK(hipEventRecord(evc[0], ls));
+      HIPCHK(hipEventRecord(evc[1], ls));
+    }
+    cp.unit_base = (int)((int64_t)units * c / C);
+    cp.n_cast_sets = (int)((int64_t)units * (c + 1) / C) - cp.unit_base;
+    rc = launchNarrow(e, dm, e->d_qchildrenR.p, e->h_qchildrenR, cp, true, slot, append != 0 || c > 0);
+    if (rc != TOHC_OK) return rc;
+  }
+  return TOHC_OK;
 }
 
 int tohc_enqueue_links_vs_all(tohc_engine *e, int filter_mask, int want_jacobians, int append) {
@@ -985,6 +1006,7 @@ static int posesQuery(tohc_engine *e, const double *obj_T, const double *cast_T1
   memset(&cp, 0, sizeof cp);
   cp.T = 1; cp.gap = 0; cp.cast = cast; cp.filter_mask = filter_mask; cp.want_jac = 0; cp.d = e->d; cp.breaking = e->breaking;
   cp.n_cast_sets = n_sets;
+  e->last_sets = n_sets;
   rc = launchNarrow(e, dm, e->d_qchildrenP.p, qch, cp, false, slot, false);
   if (rc != TOHC_OK) return rc;
   const double *g = nullptr;

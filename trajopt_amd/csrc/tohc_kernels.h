@@ -71,6 +71,7 @@ struct PairRec { int set, q, x, pad; };
 struct EpaRec { int pair; int isValid; float distance; float n[3]; float pB[3]; };
 struct HitRec { int pair; float distance; float n[3]; float pB[3]; };
 struct PenRec { EpaRec e; PenHand h; };   // k_pen -> k_epa
+#define TOHC_EPA_WAVES 2                   // k_epa is bound by the latency of dependent instructions: more resident waves, more pairs in flight
 #define TOHC_PEN_DIV 8                     // the k_pen -> k_epa queue holds 1/8 of the pair capacity
 struct Counters {  // one per enqueue
   unsigned int n_pairs[TOHC_NSHARD], n_epa[TOHC_NSHARD], n_hits[TOHC_NSHARD];
@@ -80,7 +81,8 @@ struct Counters {  // one per enqueue
 };
 
 struct CallParams {
-  int n_cast_sets;   // number of (problem, t) units enumerated
+  int n_cast_sets;   // number of (problem, t) units enumerated by this launch ...
+  int unit_base;     // ... starting at this one (an enqueue may be cut into unit ranges)
   int T, gap;        // sets per problem; cast: second pose = set + gap (robot mode); poses mode: T = 1, gap = 0
   int cast;          // 0 discrete, 1 cast
   int filter_mask;
@@ -327,7 +329,7 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS) k_broadphase(CullArgs ca) {
   __shared__ int s_q[TOHC_BP_QCAP];
   const int lane = threadIdx.x;
   const int qi = blockIdx.x % ca.nQ;
-  const int cs = blockIdx.x / ca.nQ;
+  const int cs = cp.unit_base + blockIdx.x / ca.nQ;
   const int q = ca.qchildren[qi];
   const int Q = sc.child_obj[q];
   const int shard = blockIdx.x % TOHC_NSHARD;
@@ -608,7 +610,7 @@ __global__ void __launch_bounds__(64, 2) k_pen(NarrowArgs a) {
 
 // k_epa: second stage (EPA proper) for the pairs k_pen handed over, one group of G lanes per pair, pools in LDS
 template <int G, int BLOCK>
-__global__ void __launch_bounds__(BLOCK, 2) k_epa(NarrowArgs a) {
+__global__ void __launch_bounds__(BLOCK, TOHC_EPA_WAVES) k_epa(NarrowArgs a) {
   __shared__ EpaMem mem[BLOCK / G];
   const int groupsPerBlock = BLOCK / G;
   const unsigned int gid = blockIdx.x * groupsPerBlock + threadIdx.x / G;
