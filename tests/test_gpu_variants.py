@@ -1,0 +1,147 @@
+"""GPU suite, part 2: every way the engine can be configured computes the SAME slab, bit for bit, and the rarely taken
+host / fall-back paths agree with the oracle.
+
+  * engine variants (environment switches read by tohc_create): pre-test off, one stream, enqueues cut into unit
+    ranges on four lanes, host-side canonical sort, 16-lane-group GJK, one EPA group per wavefront;
+  * several appended enqueues in one slab (the lanes' ordering events);
+  * a robot with two joints on one optimisation column (mimic joint): k_finish's lane-per-column fall-back.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bindings as B
+from trajopt_amd import model as M, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = [{}, {"TOHC_PRETEST": "0"}, {"TOHC_STREAMS": "1"}, {"TOHC_CHUNKS": "2", "TOHC_STREAMS": "4"}, {"TOHC_HOST_SORT": "1"},
+            {"TOHC_GJK_GROUP": "16"}, {"TOHC_EPA_BLOCK": "16"}, {"TOHC_GROUP": "64"}]
+
+
+def _world():
+    """Full-body robot next to a 400-hull soup and a few boxes: separated, touching and deeply penetrating pairs."""
+    s = M.Scene()
+    rb = synth.pr2_like(s, seed=0, active="fullbody")
+    synth.convex_soup(s, n_hulls=400, seed=5, extent=1.2, center=(1.1, 0.0))
+    ids, boxT = synth.add_boxes(s, [((.85, .55, .01), synth.T7((1.1, 0, .635))), ((.2, .3, .4), synth.T7((0.6, -0.6, 0.4), (0, 0, 1), 0.5))], name="box")
+    s.finalize(); rb.finalize()
+    static_T = synth.static_poses(s, ids, boxT)
+    return s, rb, static_T
+
+
+def _run(env, s, rb, static_T, dofs, Bp, Tt, allowed=None):
+    from trajopt_amd import engine
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        e = engine.Engine(0)       # the switches are read here
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        e.upload_scene(s, static_T)
+        e.upload_robot(rb)
+        if allowed is None:   # IgnoreZeroStateSelfCollisions (collision_checker.cpp:41-56): robot pairs touching at rest
+            e.set_contact_distance(0.1)
+            rec0, _ = e.links_vs_all_batch(np.zeros((1, rb.K)), 1, 1, filter_mask=M.GROUP_ROBOT, want_jacobians=False)
+            allowed = np.ones((s.n_objects, s.n_objects), np.uint8)
+            allowed[rec0["idA"], rec0["idB"]] = 0
+            allowed[rec0["idB"], rec0["idA"]] = 0
+        e.set_allowed_matrix(allowed)
+        e.set_contact_distance(0.09)
+        e.set_capacity(1 << 22, 1 << 20)
+        e.stage_dofs(dofs, Bp, Tt)
+        e.enqueue_links_vs_all(-1, True, append=False)
+        e.enqueue_cast_vs_all(1, True, append=True)
+        e.enqueue_links_vs_all(M.GROUP_KINBODY, True, append=True)   # a third and a fourth pass in the same slab
+        e.enqueue_cast_vs_all(2, True, append=True)
+        rec, g = e.fetch()
+        c = e.counters()
+        return rec, g, c, allowed
+    finally:
+        e.close()
+
+
+def test_engine_variants_compute_the_same_slab(built):
+    s, rb, static_T = _world()
+    Bp, Tt = 6, 100            # 600 units per pass: enough for the unit-range split to engage
+    dofs = np.stack([synth.fullbody_trajectory(rb, np.random.default_rng(50 + b), Tt) for b in range(Bp)])
+    ref_rec, ref_g, ref_c, allowed = _run({}, s, rb, static_T, dofs, Bp, Tt)
+    assert len(ref_rec) > 1000 and ref_c["epa_evals"] > 0 and ref_c["gjk_evals"] < ref_c["pair_evals"]
+    for env in VARIANTS[1:]:
+        rec, g, c, _ = _run(env, s, rb, static_T, dofs, Bp, Tt, allowed)
+        tag = str(env)
+        assert len(rec) == len(ref_rec), tag
+        # the canonical order leaves only exact duplicates (a robot-robot pair seen from both query links in the same
+        # GJK roles) free to swap, and those are bitwise equal
+        assert np.array_equal(rec, ref_rec), tag
+        assert np.array_equal(g, ref_g), tag
+        assert c["pair_evals"] == ref_c["pair_evals"] and c["contacts"] == ref_c["contacts"], tag
+        if env.get("TOHC_PRETEST") == "0":
+            assert c["gjk_evals"] == c["pair_evals"]
+    # and the slab is right: one problem against the oracle, pass by pass
+    w = B.oracle_world(s, cap=1 << 17)
+    w.set_contact_distance(0.09)
+    w.set_allowed(allowed)
+    b = 2
+    sel = ref_rec["problem"] == b
+    rec_b, g_b = ref_rec[sel], ref_g[sel]
+    o1, g1 = w.linearize(rb, static_T, dofs[b])
+    o2, g2 = w.linearize(rb, static_T, dofs[b], cast=True)
+    o3, g3 = w.linearize(rb, static_T, dofs[b], mask=M.GROUP_KINBODY)
+    o4, g4 = w.linearize(rb, static_T, dofs[b], cast=True, gap=2)
+    disc, cast = rec_b["cctype"] == 0, rec_b["cctype"] != 0
+    assert disc.sum() == len(o1) + len(o3) and cast.sum() == len(o2) + len(o4)
+    # same (t, pair) keys with multiplicity, same distances
+    def keys(t, a, ca, bb, cb, dist):
+        return sorted(zip(t.tolist(), a.tolist(), ca.tolist(), bb.tolist(), cb.tolist(), dist.tolist()))
+    for m, os_ in ((disc, (o1, o3)), (cast, (o2, o4))):
+        oc = np.concatenate([o["c"] for o in os_]); ot = np.concatenate([o["t"] for o in os_])
+        r = rec_b[m]
+        mine = keys(r["t"], r["idA"], r["childA"], r["idB"], r["childB"], r["dist"])
+        assert mine == keys(ot, oc["objA"], oc["childA"], oc["objB"], oc["childB"], oc["dist"].astype(np.float64))
+    w.close()
+
+
+def test_mimic_joint_falls_back_to_column_walk(built):
+    """Two revolute joints of one chain driven by the same robot DOF (mult 1 and -0.5): their Jacobian columns add
+    before the product with the normal, which only the lane-per-column epilogue does (DevRobot.fast_jac = 0)."""
+    from trajopt_amd import engine
+    s = M.Scene()
+    r = M.RobotModel()
+    base = r.add_link(-1, name="base")
+    dims = [(0.3, 0.04, 0.04, 0.3), (0.25, 0.03, 0.03, 0.25), (0.2, 0.03, 0.03, 0.2)]
+    parent, off = base, 0.0
+    for i, (hx, hy, hz, cx) in enumerate(dims):
+        obj = s.add_object([(s.add_box(hx, hy, hz), synth.T7((cx, 0, 0)))], M.GROUP_ROBOT, name="arm%d" % i)
+        dof, mult = (0, 1.0) if i == 0 else ((1, 1.0) if i == 1 else (0, -0.5))   # link 2 mimics joint 0
+        parent = r.add_link(parent, synth.T7((off, 0, 0.1 * i)), M.J_REVOLUTE, (0, 0, 1), dof=dof, mult=mult, offs=0.1 * i, obj=obj, name="arm%d" % i)
+        off = 2 * hx
+    r.set_active([0, 1])
+    ids, boxT = synth.add_boxes(s, [((.3, .3, .3), synth.T7((1.0, 0.5, 0.1))), ((.05, .6, .2), synth.T7((0.5, -0.3, 0.1)))], name="obst")
+    s.finalize(); r.finalize()
+    static_T = synth.static_poses(s, ids, boxT)
+    traj = synth.straight_line([-0.6, -0.8], [0.9, 0.7], 12)
+    e = engine.Engine(0)
+    try:
+        e.upload_scene(s, static_T)
+        e.upload_robot(r)
+        e.set_contact_distance(0.15)
+        w = B.oracle_world(s)
+        w.set_contact_distance(0.15)
+        n = 0
+        for cast in (False, True):
+            rec, g = e.cast_vs_all_batch(traj, 1, len(traj), 1) if cast else e.links_vs_all_batch(traj, 1, len(traj))
+            orec, og = w.linearize(r, static_T, traj, cast=cast)
+            util.assert_same_linearization(rec, g, orec, og, "mimic cast=%s" % cast)
+            n += len(rec)
+        assert n > 0
+        w.close()
+    finally:
+        e.close()

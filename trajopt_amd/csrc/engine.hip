@@ -914,7 +914,7 @@ int tohc_fetch(tohc_engine *e, const tohc_record **records, const double **grads
     std::vector<uint32_t> idx(n);
     std::iota(idx.begin(), idx.end(), 0u);
     const tohc_record *r = e->h_records.p;
-    std::sort(idx.begin(), idx.end(), [r](uint32_t i, uint32_t j) {
+    std::stable_sort(idx.begin(), idx.end(), [r](uint32_t i, uint32_t j) {  // stable, like the device radix sort: equal keys keep slab order
       const tohc_record &a = r[i], &b = r[j];
       if (a.problem != b.problem) return a.problem < b.problem;
       if (a.t != b.t) return a.t < b.t;
