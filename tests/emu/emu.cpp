@@ -99,6 +99,10 @@ void *emu_create(const ora_scene *sc) {
       float m = safeMargin(0.04f, p[0], p[1], p[2]);
       s.dims = mk(((p[0] * 1.0f - m) + m) - 0.0f, ((p[1] * 1.0f - m) + m) - 0.0f, ((p[2] * 1.0f - m) + m) - 0.0f);
       s.lmin = -s.dims; s.lmax = s.dims;
+    } else if (s.kind == ORA_CYLZ) {
+      float m = safeMargin(0.04f, p[0], p[0], p[1]);
+      s.dims = mk(((p[0] * 1.0f - m) + m) - 0.0f, ((p[0] * 1.0f - m) + m) - 0.0f, ((p[1] * 1.0f - m) + m) - 0.0f);
+      s.lmin = -s.dims; s.lmax = s.dims;
     } else {
       s.dims = mk(0, 0, 0);
       s.lmin = mk(INFINITY, INFINITY, INFINITY); s.lmax = mk(-INFINITY, -INFINITY, -INFINITY);

@@ -82,11 +82,12 @@ def test_golden_fixtures_bit_exact(eng, path):
         util.assert_same_contacts(util.records_to_contacts(rec), z["cast_%d" % i], "cast d=%g" % d)
 
 
-@pytest.mark.parametrize("seed,spread", [(200, 0.6), (201, 0.3), (202, 0.25), (203, 0.45), (204, 0.3), (205, 1.0)])
+@pytest.mark.parametrize("seed,spread", [(200, 0.6), (201, 0.3), (202, 0.25), (203, 0.45), (204, 0.3), (205, 1.0), (320, 0.3), (321, 0.5), (322, 0.25)])
 def test_random_scenes_vs_oracle_poses_api(eng, seed, spread):
-    """Several pose sets per call (the batch axis), discrete and cast, dense (EPA heavy) and sparse."""
+    """Several pose sets per call (the batch axis), discrete and cast, dense (EPA heavy) and sparse.
+    Seeds >= 300: half of the shapes are z-cylinders (GT_Cylinder, bullet_collision_checker.cpp:153-158)."""
     rng = np.random.default_rng(seed)
-    s, objT, robot = synth.random_scene(rng, spread=spread, n_static=8, n_robot=5)
+    s, objT, robot = synth.random_scene(rng, spread=spread, n_static=8, n_robot=5, round_prob=0.5 if seed >= 300 else 0.0)
     nsets = 4
     sets = np.stack([objT] + [np.array([synth.random_T7(rng, -spread, spread) for _ in range(len(objT))]) for _ in range(nsets - 1)])
     T1 = sets[:, robot].copy()
@@ -200,6 +201,13 @@ def test_empty_and_error_paths(eng):
     assert len(rec) == 0
     with pytest.raises(engine.EngineError):
         eng.set_contact_distance(-1.0)
+    sph = M.Scene()                                 # spheres: rejected loudly, never approximated
+    sph.add_object([(sph.add_sphere(0.1), M.IDENT7)], M.GROUP_KINBODY)
+    sph.finalize()
+    with pytest.raises(engine.EngineError, match="sphere"):
+        eng.upload_scene(sph, [M.IDENT7])
+    eng.upload_scene(s, static_T)
+    eng.upload_robot(rb)
     eng.set_capacity(16, 4)                         # too small on purpose: reported, not silently truncated
     eng.set_contact_distance(0.2)
     with pytest.raises(engine.EngineError):

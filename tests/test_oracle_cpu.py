@@ -94,10 +94,11 @@ def test_golden_fixtures_bit_exact(built, path, mk):
 
 
 @pytest.mark.skipif(not B.ref_available(), reason="oracle/_ref/libref.so is only built where /root/reference exists")
-@pytest.mark.parametrize("seed", range(100, 112))
+@pytest.mark.parametrize("seed", list(range(100, 112)) + list(range(300, 308)))
 def test_oracle_vs_reference_bullet_random(built, seed):
+    """seeds >= 300: half of the shapes are z-cylinders (GT_Cylinder, bullet_collision_checker.cpp:153-158)"""
     rng = np.random.default_rng(seed)
-    s, objT, robot = synth.random_scene(rng, spread=float(rng.choice([0.3, 0.6])))
+    s, objT, robot = synth.random_scene(rng, spread=float(rng.choice([0.3, 0.6])), round_prob=0.5 if seed >= 300 else 0.0)
     wr, wo, we = B.ref_world(s), B.oracle_world(s), util.emu_world(s)
     T1 = objT[robot].copy()
     T1[:, 4:] += rng.normal(size=(len(robot), 3)) * 0.15

@@ -377,6 +377,15 @@ int tohc_upload_scene(tohc_engine *e, int n_shapes, const int32_t *shape_kind, c
         float dim = ((p[k] * 1.0f - m) + m) - 0.0f;
         e->h_shape_dims[3 * i + k] = dim; e->h_shape_lmin[3 * i + k] = -dim; e->h_shape_lmax[3 * i + k] = dim;
       }
+    } else if (shape_kind[i] == TOHC_CYLZ) {
+      // btCylinderShapeZ(r, r, h/2): same margin round trip as the box (btCylinderShape.cpp:18-27); param = (radius, half height)
+      if (!(p[0] > 0 && p[1] > 0)) return fail(e, TOHC_E_INVALID, "upload_scene: cylinder %d has a non-positive radius or height", i);
+      const float he[3] = {p[0], p[0], p[1]};
+      float m = safeMargin(0.04f, he[0], he[1], he[2]);
+      for (int k = 0; k < 3; ++k) {
+        float dim = ((he[k] * 1.0f - m) + m) - 0.0f;
+        e->h_shape_dims[3 * i + k] = dim; e->h_shape_lmin[3 * i + k] = -dim; e->h_shape_lmax[3 * i + k] = dim;
+      }
     } else if (shape_kind[i] == TOHC_HULL) {
       int off = shape_voff[i], cnt = shape_vcnt[i];
       if (!vx || !vy || !vz || cnt < 1 || cnt > 64 || off < 0 || off + cnt > n_verts)
@@ -389,7 +398,7 @@ int tohc_upload_scene(tohc_engine *e, int n_shapes, const int32_t *shape_kind, c
       }
       for (int a = 0; a < 3; ++a) { e->h_shape_lmin[3 * i + a] = lo[a]; e->h_shape_lmax[3 * i + a] = hi[a]; }
     } else {
-      return fail(e, TOHC_E_UNSUPPORTED, "upload_scene: shape %d has kind %d; only boxes and convex hulls are supported", i, shape_kind[i]);
+      return fail(e, TOHC_E_UNSUPPORTED, "upload_scene: shape %d has kind %d; boxes, z-cylinders and convex hulls are supported (spheres: Bullet's sphere-specific algorithms are not restated)", i, shape_kind[i]);
     }
   }
   e->h_child_shape.assign(child_shape, child_shape + n_children);

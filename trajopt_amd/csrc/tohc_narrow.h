@@ -91,7 +91,7 @@ struct Grp<1> {  // one lane per pair: nothing to exchange
 };
 #endif
 
-enum { KIND_BOX = 0, KIND_HULL = 1 };
+enum { KIND_BOX = 0, KIND_HULL = 1, KIND_CYLZ = 3 };   // 2 = sphere: not supported (tohc_upload_scene rejects it)
 
 template <int G>
 struct Cvx {
@@ -138,6 +138,17 @@ TOHC_DEV void cvxLoad<1>(Cvx<1> &c, int kind, V3 dims, const float *, const floa
 }
 
 TOHC_DEV float fsel(float a, float b, float c) { return a >= 0 ? b : c; }  // btScalar.h:468-473
+// CylinderLocalSupportZ [cvx:156-215 with upAxis 2]; he = (radius, radius, half height)
+TOHC_DEV V3 cylZSupport(V3 he, V3 v) {
+  const float radius = he.x, halfHeight = he.z;
+  const float s = sqrtf(v.x * v.x + v.y * v.y);
+  const float z = (double)v.z < 0.0 ? -halfHeight : halfHeight;
+  if (s != 0.0f) {
+    const float d = radius / s;
+    return mk(v.x * d, v.y * d, z);
+  }
+  return mk(radius, 0.0f, z);
+}
 
 // btVector3::maxDot (btVector3.h:1003-1018): strict '>' from index 0 => the lowest index among equal maxima
 template <int G>
@@ -201,12 +212,14 @@ TOHC_DEV V3 cvxVertex<1>(const Cvx<1> &c, int i) {
 template <int G>
 TOHC_DEV V3 supPlainNV(const Cvx<G> &c, V3 d) {
   if (c.kind == KIND_BOX) return mk(fsel(-d.x, -c.dims.x, c.dims.x), fsel(-d.y, -c.dims.y, c.dims.y), fsel(-d.z, -c.dims.z, c.dims.z));
+  if (c.kind == KIND_CYLZ) return cylZSupport(c.dims, d);
   return hullMaxDot<G>(c, d);
 }
 // the VIRTUAL localGetSupportingVertex CastHullShape calls on its inner shape: box tie rule d >= 0 -> +h (btBoxShape.h:50-59)
 template <int G>
 TOHC_DEV V3 supPlainVirtual(const Cvx<G> &c, V3 d) {
   if (c.kind == KIND_BOX) return mk(fsel(d.x, c.dims.x, -c.dims.x), fsel(d.y, c.dims.y, -c.dims.y), fsel(d.z, c.dims.z, -c.dims.z));
+  if (c.kind == KIND_CYLZ) return cylZSupport(c.dims, d);   // btCylinderShape's virtual support + margin 0
   return hullMaxDot<G>(c, d);
 }
 template <int G>
@@ -1366,6 +1379,11 @@ TOHC_DEV void gjkOutput(const GjkState &st, float maxDist2, PairOut &o) {
 // ---------------------------------------------------------------------------------------------------------------
 template <int G>
 TOHC_DEV void averageSupport(const Cvx<G> &c, V3 nl, float &outsup, V3 &outpt) {
+  if (c.kind == KIND_CYLZ) {  // not polyhedral: the support vertex itself [bcc:124-129]
+    outpt = cylZSupport(c.dims, nl);
+    outsup = dot(nl, outpt);
+    return;
+  }
   V3 sum = mk(0, 0, 0);
   float cnt = 0, maxS = -1000;
   const float EPS = 1e-3f;

@@ -38,6 +38,14 @@ class Scene:
         """Half extents, as OpenRAVE's GetBoxExtents() (bullet_collision_checker.cpp:148)."""
         return self._shape(BOX, (hx, hy, hz, 0.0), None)
 
+    def add_sphere(self, radius):
+        """GT_Sphere -> btSphereShape(radius) (bullet_collision_checker.cpp:150-152)."""
+        return self._shape(SPHERE, (radius, 0.0, 0.0, 0.0), None)
+
+    def add_cylinder(self, radius, half_height):
+        """GT_Cylinder -> btCylinderShapeZ(r, r, height / 2) (:153-158): param = (radius, HALF height)."""
+        return self._shape(CYLZ, (radius, half_height, 0.0, 0.0), None)
+
     def add_hull(self, pts):
         """Convex hull of <= 64 points, exactly the points addPoint() would receive (:191-202)."""
         pts = np.asarray(pts, dtype=np.float32).reshape(-1, 3)

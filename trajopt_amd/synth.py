@@ -65,8 +65,9 @@ def blob_hull(rng, scale=(0.05, 0.05, 0.15), npts=200, nverts=42, center=(0, 0, 
     return pts[idx].astype(np.float32)
 
 
-def random_scene(rng, n_static=6, n_robot=4, compound_prob=0.5, box_prob=0.4, spread=0.6):
-    """A small world with mixed boxes / hulls, bare shapes and compounds.  Returns (scene, objT, robot_ids)."""
+def random_scene(rng, n_static=6, n_robot=4, compound_prob=0.5, box_prob=0.4, spread=0.6, round_prob=0.0, spheres=False):
+    """A small world with mixed boxes / hulls (and, with round_prob > 0, z-cylinders; spheres only on request -- the
+    engine rejects them), bare shapes and compounds.  Returns (scene, objT, robot_ids).  round_prob = 0 draws exactly the scenes of the golden fixtures."""
     s = M.Scene()
     objT, robot = [], []
 
@@ -74,7 +75,9 @@ def random_scene(rng, n_static=6, n_robot=4, compound_prob=0.5, box_prob=0.4, sp
         ch = []
         k = 1 if rng.random() > compound_prob else int(rng.integers(1, 4))
         for i in range(k):
-            if rng.random() < box_prob:
+            if round_prob > 0 and rng.random() < round_prob:
+                sh = s.add_sphere(rng.uniform(0.03, 0.2)) if (spheres and rng.random() < 0.5) else s.add_cylinder(rng.uniform(0.03, 0.15), rng.uniform(0.03, 0.25))
+            elif rng.random() < box_prob:
                 sh = s.add_box(*rng.uniform(0.03, 0.25, size=3))
             else:
                 sh = s.add_hull(blob_hull(rng, scale=rng.uniform(0.03, 0.15, size=3), nverts=int(rng.choice([8, 20, 42]))))
@@ -105,7 +108,7 @@ def boxbot(scene):
 
 
 def three_links(scene):
-    """data/three_links.robot.xml: planar 3R arm about z (the base cylinder is left out: no cylinder support yet)."""
+    """data/three_links.robot.xml: planar 3R arm about z (the base cylinder is left out)."""
     r = M.RobotModel()
     base = r.add_link(-1, name="Base")
     dims = [(0.08, 0.01, 0.005, 0.08), (0.08, 0.0075, 0.005, 0.08), (0.04, 0.005, 0.005, 0.04)]
