@@ -146,6 +146,18 @@ int tohc_links_vs_all_poses(tohc_engine *e, const double *obj_T, int n_sets, con
 int tohc_cast_vs_all_poses(tohc_engine *e, const double *obj_T, const double *cast_T1, int n_sets, const int32_t *query,
                            int n_query, const tohc_record **records, int *n_records);
 
+/* replaces BulletCollisionChecker::ContinuousCheckTrajectory                 bullet_collision_checker.cpp:683-753
+ * (btCollisionWorld::convexSweepTest -> btContinuousConvexCollision::calcTimeOfImpact per link geometry and segment).
+ * dofs: [B][T][K]; one record at most per (problem, segment t -> t+1, affected link geometry): the closest
+ * KinBodyFilter object hit on the way.  record: idA/childA = the swept link geometry, idB/childB = what it hits,
+ * time = hit fraction in [0,1] of the segment (the reference passes t + fraction to Collision's ctor), n = hit normal,
+ * ptA = ptB = hit point, dist = 0; no gradients.  Like the reference it ignores the allowed-pair matrix. */
+int tohc_continuous_check_trajectory(tohc_engine *e, const double *dofs, int B, int T, const tohc_record **records, int *n_records);
+/* the same on explicit poses: obj_T [n_steps][n_objects][7]; the query links sweep from step s to s+1 against the
+ * other objects' poses at step s. */
+int tohc_continuous_check_poses(tohc_engine *e, const double *obj_T, int n_steps, const int32_t *query, int n_query,
+                                const tohc_record **records, int *n_records);
+
 /* device FK only (diagnostics / tests): link_T [B*T][n_links][7] */
 int tohc_forward_kinematics(tohc_engine *e, const double *dofs, int n_cfg, double *link_T);
 

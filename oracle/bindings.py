@@ -48,6 +48,15 @@ class OraLin(C.Structure):
     _fields_ = [("t", C.c_int), ("c", OraContact), ("const0", C.c_double), ("const1", C.c_double)]
 
 
+class OraSweepHit(C.Structure):
+    _fields_ = [("obj", C.c_int), ("child", C.c_int), ("seg", C.c_int), ("hitObj", C.c_int), ("hitChild", C.c_int),
+                ("fraction", C.c_float), ("n", C.c_double * 3), ("pt", C.c_double * 3)]
+
+
+SWEEP_DTYPE = np.dtype([("obj", "i4"), ("child", "i4"), ("seg", "i4"), ("hitObj", "i4"), ("hitChild", "i4"),
+                        ("fraction", "f4"), ("n", "f8", 3), ("pt", "f8", 3)], align=True)
+assert SWEEP_DTYPE.itemsize == C.sizeof(OraSweepHit)
+
 CONTACT_DTYPE = np.dtype([
     ("objA", "i4"), ("childA", "i4"), ("objB", "i4"), ("childB", "i4"), ("cctype", "i4"), ("time", "f4"),
     ("dist", "f8"), ("n", "f8", 3), ("ptA", "f8", 3), ("ptB", "f8", 3), ("ptB1", "f8", 3)], align=True)
@@ -111,6 +120,10 @@ class World:
         f("cast_vs_all").restype = C.c_int
         f("cast_vs_all").argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int,
                                      C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(OraContact), C.c_int]
+        if hasattr(lib, prefix + "continuous_check"):   # the host emulation of the device code has it too
+            f("continuous_check").restype = C.c_int
+            f("continuous_check").argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int,
+                                              C.POINTER(C.c_double), C.c_int, C.POINTER(OraSweepHit), C.c_int]
         self.f = f
         self.cscene = make_c_scene(scene)
         self.h = f("create")(C.byref(self.cscene))
@@ -160,6 +173,33 @@ class World:
                                   _p(T1, C.c_double), self.buf.ctypes.data_as(C.POINTER(OraContact)), self.cap)
         assert n <= self.cap
         return self.buf[:n].copy()
+
+    def set_trig_mode(self, portable):
+        """oracle / emu: 0 = libm's sinf/cosf/acosf like the reference, 1 = the portable routines the device runs"""
+        self.f("set_trig_mode")(int(portable))
+
+    def continuous_check(self, objT, query, traj):
+        """ContinuousCheckTrajectory on explicit poses: traj [nsteps][len(query)][7] -> SWEEP_DTYPE[n], ordered
+        (link, geometry, segment) like the reference's loops."""
+        objT = np.ascontiguousarray(objT, np.float64).reshape(-1, 7)
+        q = np.ascontiguousarray(query, np.int32)
+        traj = np.ascontiguousarray(traj, np.float64).reshape(-1, len(q), 7)
+        out = np.zeros(self.cap, SWEEP_DTYPE)
+        n = self.f("continuous_check")(self.h, _p(objT, C.c_double), _p(q, C.c_int), len(q), _p(traj, C.c_double),
+                                       len(traj), out.ctypes.data_as(C.POINTER(OraSweepHit)), self.cap)
+        assert n <= self.cap
+        return out[:n].copy()
+
+    def sweep_pair(self, Q, qc, T0, T1, X, xc, XT):
+        """oracle only: time of impact of ONE (swept geometry, resting geometry) pair -> SWEEP_DTYPE record or None"""
+        self.lib.ora_sweep_pair.restype = C.c_int
+        self.lib.ora_sweep_pair.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int,
+                                            C.c_int, C.POINTER(C.c_double), C.POINTER(OraSweepHit)]
+        out = np.zeros(1, SWEEP_DTYPE)
+        a = [np.ascontiguousarray(t, np.float64).reshape(7) for t in (T0, T1, XT)]
+        ok = self.lib.ora_sweep_pair(self.h, int(Q), int(qc), _p(a[0], C.c_double), _p(a[1], C.c_double), int(X), int(xc),
+                                     _p(a[2], C.c_double), out.ctypes.data_as(C.POINTER(OraSweepHit)))
+        return out[0] if ok else None
 
     # -- oracle only: full linearization (FK + contacts + Jacobian projection) ---------------------------
     def counter(self, which):

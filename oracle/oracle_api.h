@@ -57,6 +57,15 @@ typedef struct ora_contact {
   double ptA[3], ptB[3], ptB1[3];
 } ora_contact;
 
+/* One hit of ContinuousCheckTrajectory (bullet_collision_checker.cpp:683-753): the reference builds
+ * Collision(link, hitLink, hitPoint, hitPoint, hitNormal, 0, 1, seg + fraction) (whose ctor then drops the time). */
+typedef struct ora_sweep_hit {
+  int obj, child;       /* the swept link and its geometry                         */
+  int seg;              /* trajectory segment seg -> seg+1                         */
+  int hitObj, hitChild; /* closest object hit (the reference reports the link only) */
+  float fraction;       /* m_closestHitFraction                                    */
+  double n[3], pt[3];   /* m_hitNormalWorld, m_hitPointWorld                       */
+} ora_sweep_hit;
 
 /* Flattened kinematic model.  OpenRAVE (FK, Jacobians) is absent from /root/reference and from this image, so the
  * conventions below are the build's own, chosen to follow what configuration_space.cpp:12-23,83-133 relies on:

@@ -360,6 +360,61 @@ int ref_cast_vs_all(void* h, const double* objT, const int* q, int nq, const dou
   return n;
 }
 
+/* ContinuousCheckTrajectory / ContinuousCheckShape (bullet_collision_checker.cpp:683-753) through the reference's own
+ * btCollisionWorld::convexSweepTest.  traj: [nsteps][nq][7] world poses of the query links. */
+namespace {
+struct ClosestWithChild : public btCollisionWorld::ClosestConvexResultCallback {
+  int hitChild;
+  ClosestWithChild() : btCollisionWorld::ClosestConvexResultCallback(btVector3(NAN, NAN, NAN), btVector3(NAN, NAN, NAN)), hitChild(0) {}
+  virtual btScalar addSingleResult(btCollisionWorld::LocalConvexResult& r, bool normalInWorldSpace) {
+    hitChild = r.m_localShapeInfo ? r.m_localShapeInfo->m_triangleIndex : 0;   // LocalInfoAdder: index of the compound child
+    return btCollisionWorld::ClosestConvexResultCallback::addSingleResult(r, normalInWorldSpace);
+  }
+};
+void sweepShape(World* w, btCollisionShape* shape, const std::vector<btTransform>& tfs, Obj* cow, int child, std::vector<ora_sweep_hit>& out) {
+  if (btConvexShape* convex = dynamic_cast<btConvexShape*>(shape)) {
+    for (int i = 0; i + 1 < (int)tfs.size(); ++i) {
+      ClosestWithChild ccc;
+      ccc.m_collisionFilterMask = ORA_GROUP_KINBODY;
+      w->world->convexSweepTest(convex, tfs[i], tfs[i + 1], ccc, 0);
+      if (ccc.hasHit()) {
+        ora_sweep_hit h;
+        memset(&h, 0, sizeof h);
+        h.obj = cow->id; h.child = child; h.seg = i;
+        h.hitObj = static_cast<const Obj*>(ccc.m_hitCollisionObject)->id;
+        h.hitChild = ccc.hitChild;
+        h.fraction = ccc.m_closestHitFraction;
+        for (int k = 0; k < 3; ++k) { h.n[k] = ccc.m_hitNormalWorld[k]; h.pt[k] = ccc.m_hitPointWorld[k]; }
+        out.push_back(h);
+      }
+    }
+  } else if (btCompoundShape* comp = dynamic_cast<btCompoundShape*>(shape)) {
+    for (int i = 0; i < comp->getNumChildShapes(); ++i) {
+      std::vector<btTransform> t2(tfs.size());
+      for (size_t k = 0; k < tfs.size(); ++k) t2[k] = tfs[k] * comp->getChildTransform(i);
+      sweepShape(w, comp->getChildShape(i), t2, cow, i, out);
+    }
+  } else
+    throw std::runtime_error("sweep: convex or compound only");
+}
+}  // namespace
+
+int ref_continuous_check(void* h, const double* objT, const int* q, int nq, const double* traj, int nsteps, ora_sweep_hit* out, int cap) {
+  World* w = (World*)h;
+  std::vector<ora_sweep_hit> v;
+  syncWorld(w, objT);
+  w->world->updateAabbs();
+  for (int i = 0; i < nq; ++i) {
+    Obj* cow = w->objs[q[i]];
+    std::vector<btTransform> tfs(nsteps);
+    for (int s = 0; s < nsteps; ++s) tfs[s] = toBt7(traj + 7 * ((size_t)s * nq + i));
+    sweepShape(w, cow->getCollisionShape(), tfs, cow, 0, v);
+  }
+  int n = (int)v.size();
+  for (int i = 0; i < n && i < cap; ++i) out[i] = v[i];
+  return n;
+}
+
 /* Post-construction vertex data of a shape, for hull shapes built elsewhere (diagnostics). */
 int ref_gjk_checks(void) { return gNumGjkChecks; }
 int ref_epa_checks(void) { return gNumDeepPenetrationChecks; }

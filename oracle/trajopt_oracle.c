@@ -1473,6 +1473,304 @@ int ora_cast_vs_all(void *h, const double *objT7, const int *q, int nq, const do
 }
 
 /* ------------------------------------------------------------------------------------------------------ */
+/* ContinuousCheckTrajectory [bcc:683-753]: per (link geometry, trajectory segment) the first time of impact  */
+/* against the KinBodyFilter objects, by btCollisionWorld::convexSweepTest [cw:994-1056] ->                   */
+/* objectQuerySingleInternal [cw:574-622,785-830] -> btContinuousConvexCollision::calcTimeOfImpact            */
+/*   [ccc] ext/bullet/src/BulletCollision/NarrowPhaseCollision/btContinuousConvexCollision.cpp:49-241         */
+/*   [tu]  ext/bullet/src/LinearMath/btTransformUtil.h:20-140                                                 */
+/*   [cs2] ext/bullet/src/BulletCollision/CollisionShapes/btCollisionShape.cpp:32-58                          */
+/* The reference's broadphase ray cull [cw:1019-1031] is left out: it is conservative whenever the contact    */
+/* distance inflates the tree boxes by >= 1 mm (3.001*d >= 0.001), so it cannot change the result.            */
+/* ------------------------------------------------------------------------------------------------------ */
+typedef struct { float x, y, z, w; } q4;
+
+static float cofac(const m3 *m, int r1, int c1, int r2, int c2) { /* btMatrix3x3.h:722-725 */
+  const float *a = &m->r[0].x;
+  return a[3 * r1 + c1] * a[3 * r2 + c2] - a[3 * r1 + c2] * a[3 * r2 + c1];
+}
+static m3 m3Inverse(const m3 *m) { /* btMatrix3x3.h:1019-1029 */
+  v3 co = V(cofac(m, 1, 1, 2, 2), cofac(m, 1, 2, 2, 0), cofac(m, 1, 0, 2, 1));
+  float det = vdot(m->r[0], co);
+  float s = 1.0f / det;
+  m3 r;
+  r.r[0] = V(co.x * s, cofac(m, 0, 2, 2, 1) * s, cofac(m, 0, 1, 1, 2) * s);
+  r.r[1] = V(co.y * s, cofac(m, 0, 0, 2, 2) * s, cofac(m, 0, 2, 1, 0) * s);
+  r.r[2] = V(co.z * s, cofac(m, 0, 1, 2, 0) * s, cofac(m, 0, 0, 1, 1) * s);
+  return r;
+}
+static q4 m3GetRotation(const m3 *m) { /* btMatrix3x3.h:448-478, scalar branch */
+  const float *e = &m->r[0].x; /* e[3*i+j] */
+  float trace = e[0] + e[4] + e[8];
+  float temp[4];
+  if (trace > 0.0f) {
+    float s = sqrtf(trace + 1.0f);
+    temp[3] = (s * 0.5f);
+    s = 0.5f / s;
+    temp[0] = ((e[3 * 2 + 1] - e[3 * 1 + 2]) * s);
+    temp[1] = ((e[3 * 0 + 2] - e[3 * 2 + 0]) * s);
+    temp[2] = ((e[3 * 1 + 0] - e[3 * 0 + 1]) * s);
+  } else {
+    int i = e[0] < e[4] ? (e[4] < e[8] ? 2 : 1) : (e[0] < e[8] ? 2 : 0);
+    int j = (i + 1) % 3;
+    int k = (i + 2) % 3;
+    float s = sqrtf(e[3 * i + i] - e[3 * j + j] - e[3 * k + k] + 1.0f);
+    temp[i] = s * 0.5f;
+    s = 0.5f / s;
+    temp[3] = (e[3 * k + j] - e[3 * j + k]) * s;
+    temp[j] = (e[3 * j + i] + e[3 * i + j]) * s;
+    temp[k] = (e[3 * k + i] + e[3 * i + k]) * s;
+  }
+  q4 q = {temp[0], temp[1], temp[2], temp[3]};
+  return q;
+}
+static float q4len2(q4 q) { return q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w; } /* btQuaternion.h:286-317 */
+static q4 q4normalize(q4 q) { /* *this /= length() -> *= 1/len, btQuaternion.h:326-380 */
+  float s = 1.0f / sqrtf(q4len2(q));
+  q4 r = {q.x * s, q.y * s, q.z * s, q.w * s};
+  return r;
+}
+static q4 q4mul(q4 a, q4 b) { /* btQuaternion.h operator*(q1, q2), scalar branch */
+  q4 r = {a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+          a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+  return r;
+}
+static m3 m3FromQuat(q4 q) { /* btMatrix3x3::setRotation, scalar branch [btMatrix3x3.h:204-269] */
+  float d = q4len2(q);
+  float s = 2.0f / d;
+  float xs = q.x * s, ys = q.y * s, zs = q.z * s;
+  float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
+  float xx = q.x * xs, xy = q.x * ys, xz = q.x * zs;
+  float yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
+  m3 r;
+  r.r[0] = V(1.0f - (yy + zz), xy - wz, xz + wy);
+  r.r[1] = V(xy + wz, 1.0f - (xx + zz), yz - wx);
+  r.r[2] = V(xz - wy, yz + wx, 1.0f - (xx + yy));
+  return r;
+}
+/* Portable float sin / cos / acos: Taylor series in IEEE double (+, *, /, sqrt only, no contraction), rounded to float.
+ * The SAME operation sequence is compiled into the device code (tohc_narrow.h) and the CPU oracle (trajopt_oracle.c), so
+ * both produce identical bits; accuracy ~1e-16, i.e. the correctly rounded float in all but ~1e-8 of the cases.
+ * sin / cos are only called with |x| <= pi/8 (ANGULAR_MOTION_THRESHOLD, btTransformUtil.h:20,58-61). */
+static double ptHorner(const double *c, int n, double x2) {
+  double r = c[n - 1];
+  for (int k = n - 2; k >= 0; --k) r = c[k] + x2 * r;
+  return r;
+}
+static float ptSin(float xf) {
+  const double c[10] = {1.0, -0.16666666666666666, 0.008333333333333333, -0.0001984126984126984, 2.7557319223985893e-06, -2.505210838544172e-08, 1.6059043836821613e-10, -7.647163731819816e-13, 2.8114572543455206e-15, -8.22063524662433e-18};
+  const double x = (double)xf;
+  return (float)(x * ptHorner(c, 10, x * x));
+}
+static float ptCos(float xf) {
+  const double c[10] = {1.0, -0.5, 0.041666666666666664, -0.001388888888888889, 2.48015873015873e-05, -2.755731922398589e-07, 2.08767569878681e-09, -1.1470745597729725e-11, 4.779477332387385e-14, -1.5619206968586225e-16};
+  const double x = (double)xf;
+  return (float)ptHorner(c, 10, x * x);
+}
+static double ptAsinD(double z) { /* |z| <= ~0.71 */
+  const double c[30] = {1.0, 0.16666666666666666, 0.075, 0.044642857142857144, 0.030381944444444444, 0.022372159090909092, 0.017352764423076924, 0.01396484375, 0.011551800896139705, 0.009761609529194078, 0.008390335809616815, 0.0073125258735988454, 0.006447210311889649, 0.005740037670841924, 0.005153309682319905, 0.004660143486915096, 0.004240907093679363, 0.003880964558837669, 0.0035692053938259347, 0.003297059503473485, 0.0030578216492580306, 0.002846178401108942, 0.00265787063820729, 0.0024894486782468836, 0.002338091892111975, 0.0022014739737101384, 0.0020776610325181676, 0.0019650336162772837, 0.0018622264064031275, 0.0017680811205154183};
+  return z * ptHorner(c, 30, z * z);
+}
+static float ptAcos(float xf) { /* xf in [-1, 1] */
+  const double PI = 3.141592653589793;
+  const double x = (double)xf;
+  if (x > 0.5) return (float)(2.0 * ptAsinD(sqrt((1.0 - x) * 0.5)));
+  if (x < -0.5) return (float)(PI - 2.0 * ptAsinD(sqrt((1.0 + x) * 0.5)));
+  return (float)(PI * 0.5 - ptAsinD(x));
+}
+/* 0: libm's float routines, what the reference calls (bit-exact against oracle/_ref); 1: the portable routines above,
+ * what the device runs (bit-exact against the GPU).  See tohc_narrow.h for why both exist. */
+static int g_trig_mode = 0;
+void ora_set_trig_mode(int portable) { g_trig_mode = portable; }
+static float oSin(float x) { return g_trig_mode ? ptSin(x) : sinf(x); }
+static float oCos(float x) { return g_trig_mode ? ptCos(x) : cosf(x); }
+static float btAcosf(float x) { /* btScalar.h:391-397 */
+  if (x < -1.0f) x = -1.0f;
+  if (x > 1.0f) x = 1.0f;
+  return g_trig_mode ? ptAcos(x) : acosf(x);
+}
+/* btTransformUtil::calculateVelocity with timeStep 1 [tu:108-139] */
+static void calcVelocity(const xf *t0, const xf *t1, v3 *linVel, v3 *angVel) {
+  *linVel = vdiv(vsub(t1->o, t0->o), 1.0f);
+  m3 inv = m3Inverse(&t0->b);
+  m3 dmat = mulMM(&t1->b, &inv);
+  q4 dorn = q4normalize(m3GetRotation(&dmat));
+  float angle = 2.0f * btAcosf(dorn.w);
+  v3 axis = V(dorn.x, dorn.y, dorn.z);
+  float len = vlen2(axis);
+  if (len < SIMD_EPSILON * SIMD_EPSILON) axis = V(1, 0, 0);
+  else axis = vdiv(axis, sqrtf(len));
+  *angVel = vdiv(vscale(axis, angle), 1.0f);
+}
+/* btTransformUtil::integrateTransform [tu:42-78] */
+static xf integrateTransform(const xf *cur, v3 linvel, v3 angvel, float timeStep) {
+  const float AMT = 0.5f * (6.283185307179586232f * 0.25f); /* ANGULAR_MOTION_THRESHOLD = 0.5*SIMD_HALF_PI */
+  xf out;
+  out.o = vadd(cur->o, vscale(linvel, timeStep));
+  v3 axis;
+  float fAngle = vlen(angvel);
+  if (fAngle * timeStep > AMT) fAngle = AMT / timeStep;
+  if (fAngle < 0.001f) axis = vscale(angvel, 0.5f * timeStep - (timeStep * timeStep * timeStep) * (0.020833333333f) * fAngle * fAngle);
+  else axis = vscale(angvel, oSin(0.5f * fAngle * timeStep) / fAngle);
+  q4 dorn = {axis.x, axis.y, axis.z, oCos(fAngle * timeStep * 0.5f)};
+  q4 orn0 = m3GetRotation(&cur->b);
+  q4 pred = q4normalize(q4mul(dorn, orn0));
+  out.b = m3FromQuat(pred);
+  return out;
+}
+/* btCollisionShape::getAngularMotionDisc [cs2:32-58] over getAabb(identity) of each kind: btTransformAabb with the
+ * patched SHAPE_EXPANSION [lm btAabbUtil2.h:182-207]; a hull's cached local box still carries the 0.04 construction
+ * margin (recalcLocalAabb at addPoint time, btPolyhedralConvexShape.cpp:449-478; setMargin(0) does not recompute it) */
+static float angularMotionDisc(const shape_t *s, float d) {
+  v3 mn, mx;
+  if (s->kind == ORA_SPHERE) { /* btSphereShape::getAabb: centre +- margin, no expansion */
+    mn = V(0 - s->margin, 0 - s->margin, 0 - s->margin);
+    mx = V(0 + s->margin, 0 + s->margin, 0 + s->margin);
+  } else if (s->kind == ORA_HULL) {
+    const float CDM = 0.04f;
+    v3 lmax = V(s->lmax.x + CDM, s->lmax.y + CDM, s->lmax.z + CDM), lmin = V(s->lmin.x - CDM, s->lmin.y - CDM, s->lmin.z - CDM);
+    v3 he = vscale(vsub(lmax, lmin), 0.5f);
+    he = vadd(he, vadd(V(s->margin, s->margin, s->margin), V(d, d, d)));
+    v3 lc = vscale(vadd(lmax, lmin), 0.5f);
+    v3 c = V(1.0f * lc.x + 0.0f * lc.y + 0.0f * lc.z + 0.0f, 0.0f * lc.x + 1.0f * lc.y + 0.0f * lc.z + 0.0f, 0.0f * lc.x + 0.0f * lc.y + 1.0f * lc.z + 0.0f);
+    mn = vsub(c, he); mx = vadd(c, he);
+  } else { /* box, cylinder: btTransformAabb(halfExtentsWithoutMargin, margin, identity) */
+    v3 he = vadd(vadd(s->dims, V(s->margin, s->margin, s->margin)), V(d, d, d));
+    mn = vsub(V(0, 0, 0), he); mx = vadd(V(0, 0, 0), he);
+  }
+  float radius = vlen(vsub(mx, mn)) * 0.5f;
+  v3 center = vscale(vadd(mn, mx), 0.5f);
+  return radius + vlen(center);
+}
+
+/* calcTimeOfImpact [ccc:90-241] with B at rest (fromB == toB); returns 1 on a hit */
+static int timeOfImpact(const world_t *w, const shape_t *sA, const xf *fromA, const xf *toA, const shape_t *sB, const xf *tB, float *fraction,
+                        v3 *normal, v3 *hitPoint) {
+  v3 linVelA, angVelA, linVelB, angVelB;
+  calcVelocity(fromA, toA, &linVelA, &angVelA);
+  calcVelocity(tB, tB, &linVelB, &angVelB);
+  float boundingRadiusA = angularMotionDisc(sA, w->d);
+  float boundingRadiusB = angularMotionDisc(sB, w->d);
+  float maxAngularProjectedVelocity = vlen(angVelA) * boundingRadiusA + vlen(angVelB) * boundingRadiusB;
+  v3 relLinVel = vsub(linVelB, linVelA);
+  float relLinVelocLength = vlen(vsub(linVelB, linVelA));
+  if ((relLinVelocLength + maxAngularProjectedVelocity) == 0.f) return 0;
+  float lambda = 0.f;
+  v3 n = V(0, 0, 0), c;
+  float lastLambda = lambda;
+  int numIter = 0;
+  const int maxIter = 64;
+  const float radius = 0.001f;
+  cvx_t A = plainCvx(sA), B = plainCvx(sB);
+  gjkout_t o;
+  gjkPair(&A, &B, fromA, tB, BT_LARGE_FLOAT, &o); /* computeClosestPoints [ccc:49-59]: m_maximumDistanceSquared = BT_LARGE_FLOAT */
+  if (!o.valid) return 0;
+  c = o.pointOnB;
+  float dist = o.distance + 0.0f; /* + result.m_allowedPenetration */
+  n = o.normalOnB;
+  float projectedLinearVelocity = vdot(relLinVel, n);
+  if ((projectedLinearVelocity + maxAngularProjectedVelocity) <= SIMD_EPSILON) return 0;
+  while (dist > radius) {
+    projectedLinearVelocity = vdot(relLinVel, n);
+    if ((projectedLinearVelocity + maxAngularProjectedVelocity) <= SIMD_EPSILON) return 0;
+    float dLambda = dist / (projectedLinearVelocity + maxAngularProjectedVelocity);
+    lambda = lambda + dLambda;
+    if (lambda > 1.0f) return 0;
+    if (lambda < 0.0f) return 0;
+    if (lambda <= lastLambda) return 0;
+    lastLambda = lambda;
+    xf iA = integrateTransform(fromA, linVelA, angVelA, lambda);
+    xf iB = integrateTransform(tB, linVelB, angVelB, lambda);
+    gjkPair(&A, &B, &iA, &iB, BT_LARGE_FLOAT, &o);
+    if (o.valid) {
+      dist = o.distance + 0.0f;
+      c = o.pointOnB;
+      n = o.normalOnB;
+    } else
+      return 0;
+    numIter++;
+    if (numIter > maxIter) return 0;
+  }
+  *fraction = lambda;
+  *normal = n;
+  *hitPoint = c;
+  return 1;
+}
+
+/* one (swept geometry, other geometry) pair of the sweep below, for checking the reference's choice among equal
+ * fractions: link Q's geometry qc moves from T0_7 to T1_7 (link poses), object X's geometry xc rests at XT7 */
+int ora_sweep_pair(void *h, int Q, int qc, const double *T0_7, const double *T1_7, int X, int xc, const double *XT7, ora_sweep_hit *out) {
+  world_t *w = (world_t *)h;
+  xf t0 = xfFrom7(T0_7), t1 = xfFrom7(T1_7), tX = xfFrom7(XT7);
+  if (w->obj_compound[Q]) {
+    t0 = xfMul(&t0, &w->child_T[w->obj_off[Q] + qc]);
+    t1 = xfMul(&t1, &w->child_T[w->obj_off[Q] + qc]);
+  }
+  xf tx = childWorld(w, X, xc, &tX);
+  float fr;
+  v3 nrm, pt;
+  if (!timeOfImpact(w, &w->shapes[w->child_shape[w->obj_off[Q] + qc]], &t0, &t1, &w->shapes[w->child_shape[w->obj_off[X] + xc]], &tx, &fr, &nrm, &pt)) return 0;
+  if (!(vlen2(nrm) > 0.0001f)) return 0;
+  nrm = vdiv(nrm, vlen(nrm));
+  memset(out, 0, sizeof *out);
+  out->obj = Q; out->child = qc; out->hitObj = X; out->hitChild = xc; out->fraction = fr;
+  out->n[0] = nrm.x; out->n[1] = nrm.y; out->n[2] = nrm.z;
+  out->pt[0] = pt.x; out->pt[1] = pt.y; out->pt[2] = pt.z;
+  return 1;
+}
+
+/* traj7: [nsteps][nq][7] world poses of the query links; the other objects stay at objT7.  One hit at most per
+ * (link, geometry, segment): the closest one; ties go to the lowest (object, geometry) -- the reference takes the first
+ * in DBVT traversal order, which is history dependent. */
+int ora_continuous_check(void *h, const double *objT7, const int *q, int nq, const double *traj7, int nsteps, ora_sweep_hit *out, int cap) {
+  world_t *w = (world_t *)h;
+  int n = 0;
+  xf *T = (xf *)malloc(sizeof(xf) * (w->n_objects + 1));
+  for (int i = 0; i < w->n_objects; ++i) T[i] = xfFrom7(objT7 + 7 * i);
+  for (int qi = 0; qi < nq; ++qi) {
+    int Q = q[qi];
+    for (int qc = 0; qc < w->obj_cnt[Q]; ++qc) { /* ContinuousCheckShape [bcc:683-705] */
+      const shape_t *sq = &w->shapes[w->child_shape[w->obj_off[Q] + qc]];
+      for (int seg = 0; seg + 1 < nsteps; ++seg) {
+        xf t0 = xfFrom7(traj7 + 7 * ((size_t)seg * nq + qi)), t1 = xfFrom7(traj7 + 7 * ((size_t)(seg + 1) * nq + qi));
+        if (w->obj_compound[Q]) { /* rightMultiplyAll [bcc:674-678] */
+          t0 = xfMul(&t0, &w->child_T[w->obj_off[Q] + qc]);
+          t1 = xfMul(&t1, &w->child_T[w->obj_off[Q] + qc]);
+        }
+        float closest = 1.0f; /* ConvexResultCallback::m_closestHitFraction */
+        ora_sweep_hit hit;
+        memset(&hit, 0, sizeof hit);
+        int have = 0;
+        for (int X = 0; X < w->n_objects; ++X) {
+          if (!(w->obj_group[X] & ORA_GROUP_KINBODY)) continue; /* ccc.m_collisionFilterMask = KinBodyFilter [bcc:688] */
+          for (int xc = 0; xc < w->obj_cnt[X]; ++xc) {
+            if (closest == 0.0f) break; /* btSingleSweepCallback::process [cw:969-971] (per object there; same result) */
+            xf tx = childWorld(w, X, xc, &T[X]);
+            const shape_t *sx = &w->shapes[w->child_shape[w->obj_off[X] + xc]];
+            float fr;
+            v3 nrm, pt;
+            if (!timeOfImpact(w, sq, &t0, &t1, sx, &tx, &fr, &nrm, &pt)) continue;
+            if (!(vlen2(nrm) > 0.0001f)) continue; /* [cw:601] */
+            if (!(fr < closest)) continue;           /* [cw:603] */
+            nrm = vdiv(nrm, vlen(nrm));              /* castResult.m_normal.normalize() */
+            closest = fr;
+            have = 1;
+            hit.obj = Q; hit.child = qc; hit.seg = seg; hit.hitObj = X; hit.hitChild = xc; hit.fraction = fr;
+            hit.n[0] = nrm.x; hit.n[1] = nrm.y; hit.n[2] = nrm.z;
+            hit.pt[0] = pt.x; hit.pt[1] = pt.y; hit.pt[2] = pt.z;
+          }
+        }
+        if (have) {
+          if (n < cap) out[n] = hit;
+          ++n;
+        }
+      }
+    }
+  }
+  free(T);
+  return n;
+}
+
+/* ------------------------------------------------------------------------------------------------------ */
 /* FK, point Jacobian and contact -> affine expression (fp64)                                                */
 /*   [cs:12-23,83-133] delegate to OpenRAVE, which is absent: conventions are documented in oracle_api.h.   */
 /*   [ct:37-80] CollisionsToDistanceExpressions.                                                             */

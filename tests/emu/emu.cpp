@@ -219,6 +219,51 @@ int emu_cast_vs_all(void *h, const double *objT7, const int *q, int nq, const do
   }
   return n;
 }
+// ContinuousCheckTrajectory with the device's timeOfImpact<1> (same loops and tie rule as ora_continuous_check)
+int emu_continuous_check(void *h, const double *objT7, const int *q, int nq, const double *traj7, int nsteps, ora_sweep_hit *out, int cap) {
+  World *w = (World *)h;
+  static EpaMem mem;
+  int n = 0, no = (int)w->off.size();
+  std::vector<Xf> T(no);
+  for (int i = 0; i < no; ++i) T[i] = xfFrom7(objT7 + 7 * i);
+  for (int qi = 0; qi < nq; ++qi) {
+    int Q = q[qi];
+    for (int qc = 0; qc < w->cnt[Q]; ++qc) {
+      Cvx<1> cq; load(w, w->off[Q] + qc, cq);
+      const Shape &sq = w->shapes[w->child_shape[w->off[Q] + qc]];
+      const float discA = angularMotionDisc(sq.kind, sq.dims, sq.lmin, sq.lmax, w->d);
+      for (int seg = 0; seg + 1 < nsteps; ++seg) {
+        Xf t0 = xfFrom7(traj7 + 7 * ((size_t)seg * nq + qi)), t1 = xfFrom7(traj7 + 7 * ((size_t)(seg + 1) * nq + qi));
+        if (w->compound[Q]) { t0 = xfMul(t0, w->child_T[w->off[Q] + qc]); t1 = xfMul(t1, w->child_T[w->off[Q] + qc]); }
+        float closest = 1.0f;
+        bool have = false;
+        ora_sweep_hit hit;
+        memset(&hit, 0, sizeof hit);
+        for (int X = 0; X < no; ++X) {
+          if (!(w->group[X] & ORA_GROUP_KINBODY)) continue;
+          for (int xc = 0; xc < w->cnt[X]; ++xc) {
+            if (closest == 0.0f) break;
+            Xf tx = childWorld(w, X, xc, T[X]);
+            Cvx<1> cx; load(w, w->off[X] + xc, cx);
+            const Shape &sx = w->shapes[w->child_shape[w->off[X] + xc]];
+            SweepOut so;
+            if (!timeOfImpact<1>(&mem, cq, discA, t0, t1, cx, angularMotionDisc(sx.kind, sx.dims, sx.lmin, sx.lmax, w->d), tx, so)) continue;
+            if (!(so.fraction < closest)) continue;
+            closest = so.fraction;
+            have = true;
+            hit.obj = Q; hit.child = qc; hit.seg = seg; hit.hitObj = X; hit.hitChild = xc; hit.fraction = so.fraction;
+            hit.n[0] = so.normal.x; hit.n[1] = so.normal.y; hit.n[2] = so.normal.z;
+            hit.pt[0] = so.point.x; hit.pt[1] = so.point.y; hit.pt[2] = so.point.z;
+          }
+        }
+        if (have) { if (n < cap) out[n] = hit; ++n; }
+      }
+    }
+  }
+  return n;
+}
+float emu_pt_trig(int which, float x) { return which == 0 ? ptSin(x) : which == 1 ? ptCos(x) : ptAcos(x); }
+void emu_set_trig_mode(int portable) { emuTrigMode() = portable; }
 long emu_stat(int i) {
   const EmuStats &s = emuStats();
   const long *p = &s.gjk2_calls;

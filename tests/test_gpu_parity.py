@@ -108,6 +108,81 @@ def test_random_scenes_vs_oracle_poses_api(eng, seed, spread):
     w.close()
 
 
+def _assert_same_sweeps(rec, hits, tag):
+    """GPU records vs oracle hits, BIT FOR BIT.  The oracle runs in portable-trig mode (set_trig_mode(1)): the device
+    cannot call glibc's sinf / cosf / acosf and the advancement is chaotically sensitive to their last bit, so both
+    sides use the same fp64-series routines here; in libm mode the oracle is bit-exact against the reference's Bullet
+    (tests/test_oracle_cpu.py)."""
+    rk = [(int(r["t"]), int(r["idA"]), int(r["childA"])) for r in rec]
+    hk = [(int(h["seg"]), int(h["obj"]), int(h["child"])) for h in hits]
+    assert sorted(rk) == sorted(hk), "%s: hit sets differ: %s" % (tag, sorted(set(rk) ^ set(hk))[:8])
+    byk = {k: h for k, h in zip(hk, hits)}
+    exact = 0
+    for k, r in zip(rk, rec):
+        h = byk[k]
+        assert np.float32(r["time"]) == h["fraction"], (tag, k, r["time"], h["fraction"])
+        assert (int(r["idB"]), int(r["childB"])) == (int(h["hitObj"]), int(h["hitChild"])), (tag, k)
+        assert np.array_equal(r["n"], h["n"]) and np.array_equal(r["ptA"], h["pt"]), (tag, k, r["n"], h["n"], r["ptA"], h["pt"])
+        assert np.array_equal(r["ptA"], r["ptB"]) and r["dist"] == 0
+    return len(rk)
+
+
+def test_reference_continuous_check_known_answer(eng):
+    # collision-checker-unit.cpp:102-120: boxbot swept from (-1.9, 0) to (0, 1.9) past the unit box -> one collision,
+    # robot normal (-1, 0, 0)
+    s = M.Scene()
+    b = s.add_box(.5, .5, .5)
+    s.add_object([(b, M.IDENT7)], M.GROUP_KINBODY)
+    bot = s.add_object([(b, M.IDENT7)], M.GROUP_ROBOT)
+    s.finalize()
+    eng.upload_scene(s, [T(0), T(0)])
+    eng.set_contact_distance(0.05)
+    rec = eng.continuous_check_poses([[T(0), T(-1.9, 0)], [T(0), T(0, 1.9)]], [bot])
+    assert len(rec) == 1
+    robot_normal = (1 if rec[0]["idA"] == bot else -1) * rec[0]["n"]
+    assert np.allclose(robot_normal, (-1, 0, 0), atol=1e-4)
+    assert np.float32(rec[0]["time"]) == np.float32(0.4736842)     # the reference Bullet's own fraction (oracle/_ref)
+    # through the robot model: boxbot has the affine DOFs x, y (cast-cost-unit.cpp:44, RobotAndDOF(boxbot, [], DOF_X|DOF_Y))
+    s2 = M.Scene()
+    b2 = s2.add_box(.5, .5, .5)
+    s2.add_object([(b2, M.IDENT7)], M.GROUP_KINBODY)
+    rb = synth.boxbot(s2)
+    s2.finalize(); rb.finalize()
+    eng.upload_scene(s2, np.tile(np.array(M.IDENT7), (s2.n_objects, 1)))
+    eng.upload_robot(rb)
+    rec2 = eng.continuous_check_trajectory(np.array([[-1.9, 0.0], [0.0, 1.9], [1.9, 3.8]]), 1, 3)
+    assert len(rec2) == 1 and rec2[0]["t"] == 0 and np.float32(rec2[0]["time"]) == np.float32(0.4736842)
+    # a trajectory that stays clear reports nothing (what cast-cost-unit.cpp:75-77 asserts after optimisation)
+    assert len(eng.continuous_check_trajectory(np.array([[-1.9, 0.0], [-1.9, 1.9], [1.9, 3.8]]), 1, 3)) == 0
+
+
+@pytest.mark.parametrize("seed,spread", [(500, 0.8), (501, 1.5), (502, 0.4), (503, 1.5), (504, 0.8), (505, 0.6)])
+def test_continuous_check_random_scenes_vs_oracle(eng, seed, spread):
+    """ContinuousCheckTrajectory on explicit poses (boxes, hulls, cylinders, compounds) against the CPU oracle, which is
+    bit-exact against the reference's convexSweepTest (tests/test_oracle_cpu.py)."""
+    rng = np.random.default_rng(seed)
+    s, objT, robot = synth.random_scene(rng, spread=spread, n_static=8, n_robot=5, round_prob=0.3 if seed % 2 else 0.0)
+    nst = 5
+    traj = np.stack([np.array([synth.random_T7(rng, -spread, spread) for _ in robot]) for _ in range(nst)])
+    sets = np.tile(objT[None], (nst, 1, 1))
+    sets[:, robot] = traj
+    eng.upload_scene(s, objT)
+    w = B.oracle_world(s)
+    w.set_trig_mode(1)
+    total = 0
+    try:
+        for d in (0.0, 0.05):
+            eng.set_contact_distance(d)
+            w.set_contact_distance(d)
+            rec = eng.continuous_check_poses(sets, robot)
+            hits = w.continuous_check(objT, robot, traj)
+            total += _assert_same_sweeps(rec, hits, "seed %d d=%g" % (seed, d))
+    finally:
+        w.set_trig_mode(0)
+        w.close()
+    assert total > 0
+
+
 def _arm_world(active, boxes, seed=0):
     s = M.Scene()
     rb = synth.pr2_like(s, seed=seed, active=active)
@@ -269,5 +344,33 @@ def test_fullsize_soup_properties(built):
         r = recc[recc["t"] == t].copy()
         r["t"] = 0
         util.assert_same_linearization(r, gc[recc["t"] == t], orec, og, "soup cast t=%d" % t)
+    # ContinuousCheckTrajectory of the whole trajectory: determinism, one hit at most per (segment, link geometry),
+    # fractions in [0, 1], unit normals, KinBody objects only; spot check of two segments against the oracle (which has
+    # no cull: every one of the 4096 soup hulls goes through the advancement) for a handful of links
+    sw = eng.continuous_check_trajectory(traj, 1, 100)
+    assert np.array_equal(sw, eng.continuous_check_trajectory(traj, 1, 100))
+    keys = list(zip(sw["t"].tolist(), sw["idA"].tolist(), sw["childA"].tolist()))
+    assert len(sw) > 0 and len(set(keys)) == len(keys)
+    assert (sw["time"] >= 0).all() and (sw["time"] <= 1).all() and (sw["t"] < 99).all()
+    assert np.allclose(np.linalg.norm(sw["n"], axis=1), 1, atol=1e-5)
+    assert (np.asarray(s.arrays["obj_group"])[sw["idB"]] & M.GROUP_KINBODY).all()
+    # a trajectory sharded by timestep (with the one-waypoint halo) gives the same hits
+    sub = eng.continuous_check_trajectory(traj[30:41], 1, 11)
+    sel = (sw["t"] >= 30) & (sw["t"] < 40)
+    assert np.array_equal(sub["time"], sw[sel]["time"]) and np.array_equal(sub["idB"], sw[sel]["idB"]) and np.array_equal(sub["n"], sw[sel]["n"])
+    fk = eng.forward_kinematics(traj)
+    links = [i for i, o in enumerate(rb.link_obj) if o >= 0]
+    hit_links = sorted(set(sw["idA"].tolist()))
+    objs = (hit_links[:3] + [o for o in (rb.link_obj[i] for i in links) if o not in hit_links][:2])
+    lk = [list(rb.link_obj).index(o) for o in objs]
+    w.set_trig_mode(1)
+    try:
+        for seg in (int(sw["t"][0]), int(sw["t"][len(sw) // 2])):
+            hits = w.continuous_check(static_T, objs, fk[seg:seg + 2][:, lk])
+            mine = sw[(sw["t"] == seg) & np.isin(sw["idA"], objs)].copy()
+            mine["t"] = 0
+            _assert_same_sweeps(mine, hits, "soup sweep seg %d" % seg)
+    finally:
+        w.set_trig_mode(0)
     w.close()
     eng.close()

@@ -115,6 +115,91 @@ def test_oracle_vs_reference_bullet_random(built, seed):
         w.close()
 
 
+@pytest.mark.parametrize("mk", WORLDS)
+def test_reference_continuous_check_known_answer(built, mk):
+    """collision-checker-unit.cpp:102-120: boxbot swept from (-1.9, 0) to (0, 1.9) past the unit box at the origin:
+    one collision whose robot normal is (-1, 0, 0)."""
+    s = M.Scene()
+    b = s.add_box(.5, .5, .5)
+    s.add_object([(b, M.IDENT7)], M.GROUP_KINBODY)
+    bot = s.add_object([(b, M.IDENT7)], M.GROUP_ROBOT)
+    s.finalize()
+    w = mk(s)
+    w.set_contact_distance(0.05)
+    T = lambda x, y: (1, 0, 0, 0, x, y, 0)
+    h = w.continuous_check([T(0, 0), T(-1.9, 0)], [bot], [[T(-1.9, 0)], [T(0, 1.9)]])
+    assert len(h) == 1 and h[0]["obj"] == bot and h[0]["hitObj"] == 0
+    assert np.allclose(h[0]["n"], (-1, 0, 0), atol=1e-4)
+    assert h[0]["fraction"] == np.float32(0.4736842)      # what the reference's own Bullet returns (oracle/_ref)
+    assert len(w.continuous_check([T(0, 0), T(-1.9, 0)], [bot], [[T(-1.9, 0)], [T(-1.9, 1.9)]])) == 0
+    w.close()
+
+
+@pytest.mark.skipif(not B.ref_available(), reason="oracle/_ref/libref.so is only built where /root/reference exists")
+@pytest.mark.parametrize("seed", range(400, 412))
+def test_continuous_check_oracle_vs_reference_bullet(built, seed):
+    """ContinuousCheckTrajectory: the C restatement and the host build of the DEVICE code (emu) against the reference's
+    own btCollisionWorld::convexSweepTest, bit for bit.  Where several objects share the smallest fraction (0: already
+    touching at the start of the segment) the reference reports the first in DBVT order, which is history dependent;
+    there its choice is checked pair by pair (ora_sweep_pair) instead."""
+    rng = np.random.default_rng(seed)
+    s, objT, robot = synth.random_scene(rng, spread=float(rng.choice([0.4, 0.8, 1.5])), round_prob=0.3 if seed % 2 else 0.0)
+    nst = 4
+    traj = np.stack([np.array([synth.random_T7(rng, -0.8, 0.8) for _ in robot]) for _ in range(nst)])
+    wr, wo, we = B.ref_world(s), B.oracle_world(s), util.emu_world(s)
+    n = 0
+    for d in (0.0, 0.05):
+        for w in (wr, wo, we):
+            w.set_contact_distance(d)
+        a, o, e = (w.continuous_check(objT, robot, traj) for w in (wr, wo, we))
+        assert o.tobytes() == e.tobytes()
+        key = lambda h: [(int(x["obj"]), int(x["child"]), int(x["seg"]), float(x["fraction"])) for x in h]
+        assert key(a) == key(o)
+        for x, y in zip(a, o):
+            if x.tobytes() == y.tobytes():
+                continue
+            assert x["fraction"] == 0 and (x["hitObj"], x["hitChild"]) > (y["hitObj"], y["hitChild"])   # a tie, oracle = lowest
+            qi = list(robot).index(int(x["obj"]))
+            p = wo.sweep_pair(x["obj"], x["child"], traj[x["seg"], qi], traj[x["seg"] + 1, qi], x["hitObj"], x["hitChild"], objT[x["hitObj"]])
+            assert p is not None and p["fraction"] == 0 and np.array_equal(p["n"], x["n"]) and np.array_equal(p["pt"], x["pt"])
+        n += len(a)
+    assert n > 0 or seed in (400,)      # (a sparse draw: nothing is hit)
+    for w in (wr, wo, we):
+        w.close()
+
+
+def test_portable_trig_is_correctly_rounded_and_shared(built):
+    """The device cannot call glibc's sinf / cosf / acosf; it runs portable fp64-series routines (tohc_narrow.h).  Here:
+    they return the correctly rounded float over the ranges the advancement uses, and the oracle / the host build of the
+    device code, switched to them, still agree bit for bit (what makes the GPU test bit-exact)."""
+    import ctypes as C
+    lib = C.CDLL(os.path.join(util.ROOT, "tests", "emu", "libemu.so"))
+    lib.emu_pt_trig.restype = C.c_float
+    lib.emu_pt_trig.argtypes = [C.c_int, C.c_float]
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.uniform(-0.4, 0.4, 4000), rng.uniform(-1e-3, 1e-3, 500), [0.0, 0.39269908, -0.39269908]]).astype(np.float32)
+    for x in xs:
+        assert np.float32(lib.emu_pt_trig(0, float(x))) == np.float32(np.sin(np.float64(x)))
+        assert np.float32(lib.emu_pt_trig(1, float(x))) == np.float32(np.cos(np.float64(x)))
+    ws = np.concatenate([rng.uniform(-1, 1, 4000), 1 - rng.uniform(0, 1e-5, 1000), [1.0, -1.0, 0.0, 0.5, -0.5, 0.99999994]]).astype(np.float32)
+    for w in ws:
+        assert np.float32(lib.emu_pt_trig(2, float(w))) == np.float32(np.arccos(np.float64(w))), w
+    rng = np.random.default_rng(431)
+    s, objT, robot = synth.random_scene(rng, spread=0.8, round_prob=0.3)
+    traj = np.stack([np.array([synth.random_T7(rng, -0.8, 0.8) for _ in robot]) for _ in range(4)])
+    wo, we = B.oracle_world(s), util.emu_world(s)
+    try:
+        for w in (wo, we):
+            w.set_trig_mode(1)
+            w.set_contact_distance(0.05)
+        o, e = wo.continuous_check(objT, robot, traj), we.continuous_check(objT, robot, traj)
+        assert len(o) > 0 and o.tobytes() == e.tobytes()
+    finally:
+        for w in (wo, we):
+            w.set_trig_mode(0)
+            w.close()
+
+
 def test_allowed_matrix_and_filter_mask(built):
     rng = np.random.default_rng(7)
     s, objT, robot = synth.random_scene(rng, spread=0.3)

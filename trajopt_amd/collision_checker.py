@@ -26,7 +26,7 @@ RobotFilter, KinBodyFilter = 1, 2
 class Collision:
     """collision_checker.hpp:19-29.  linkA/linkB are object ids (the C++ adapter maps them to KinBody::Link*)."""
     __slots__ = ("linkA", "linkB", "ptA", "ptB", "normalB2A", "ptB1", "distance", "weight", "time", "cctype",
-                 "childA", "childB")
+                 "childA", "childB", "toi")
 
     def __init__(self, linkA, linkB, ptA, ptB, normalB2A, distance, weight=1.0, time=0.0):
         self.linkA, self.linkB = linkA, linkB
@@ -167,7 +167,20 @@ class HIPCollisionChecker:
         collisions.extend(_collisions_from_records(rec))
 
     def ContinuousCheckTrajectory(self, traj, rad, collisions):
-        raise RuntimeError("not implemented")   # collision_checker.hpp:59 default; SURVEY.md 8(f1) "next"
+        """bullet_collision_checker.cpp:708-753: per affected link geometry and trajectory segment the first object
+        hit on the way (conservative advancement on the GPU).  Appends Collision(link, hitLink, hitPoint, hitPoint,
+        hitNormal, 0, 1, seg + fraction); like the reference's constructor the Collision keeps time = 0
+        (collision_checker.hpp:28), so the time of impact is also stored as `.toi`."""
+        traj = np.ascontiguousarray(traj, float).reshape(-1, self.robot.K)
+        rec = self.eng.continuous_check_trajectory(traj, 1, len(traj))
+        # the reference's order: link, geometry, segment (ContinuousCheckShape recursion, :683-705)
+        order = np.lexsort((rec["t"], rec["childA"], rec["idA"]))
+        for r in rec[order]:
+            c = Collision(int(r["idA"]), int(r["idB"]), r["ptA"].copy(), r["ptB"].copy(), r["n"].copy(), 0.0, 1.0,
+                          float(r["t"]) + float(r["time"]))
+            c.childA, c.childB = int(r["childA"]), int(r["childB"])
+            c.toi = float(np.float32(r["t"]) + np.float32(r["time"]))
+            collisions.append(c)
 
     def RayCastCollision(self, point1, point2):
         raise RuntimeError("not implemented")   # SURVEY.md 8(f4) "next"

@@ -786,6 +786,60 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
   return TOHC_OK;
 }
 
+// ContinuousCheckTrajectory: one k_sweep launch writes the records itself (no pair list, no k_finish); always a new slab
+static int launchSweep(tohc_engine *e, const DynMap &dm, const int *d_qchildren, const std::vector<int> &h_qchildren, CallParams cp, bool robotMode,
+                       int slot) {
+  const int nQ = (int)h_qchildren.size();
+  tohc_engine::Lane &ln = e->lane[slot % e->n_lanes];
+  hipStream_t s = ln.stream;
+  hipEvent_t *ev = &e->events[(size_t)slot * NEV];
+  HIPCHK(hipStreamWaitEvent(s, e->ev_fk, 0));
+  for (auto &other : e->lane)
+    if (&other != &ln) HIPCHK(hipStreamWaitEvent(s, other.done, 0));
+  HIPCHK(hipMemsetAsync(e->d_cnt.p + slot, 0, sizeof(Counters), s));
+  HIPCHK(hipMemsetAsync(e->d_nrec.p, 0, sizeof(unsigned int), s));
+  cp.seg_cap = (unsigned int)(e->max_pairs / TOHC_NSHARD); cp.max_records = (unsigned int)e->max_records;
+  cp.dbg_max_iter = 1000;
+  HIPCHK(e->d_records.reserve(e->max_records));
+  HIPCHK(hipEventRecord(ev[2], s));
+  if (nQ > 0 && cp.n_cast_sets > 0) {
+    const size_t blocks = (size_t)cp.n_cast_sets * nQ;
+    if (blocks > 0x7fffffffull) return fail(e, TOHC_E_CAPACITY, "sweep grid too large (%zu blocks)", blocks);
+    // what the advancement may add to a resting geometry's reach: it is "integrated" with the rotation of
+    // R * inverse(R), a few ulp away from identity, i.e. an angle of up to ~2e-3 rad about its origin
+    float discMax = 0;
+    for (int c = 0; c < e->n_children; ++c) {
+      const int sh = e->h_child_shape[c];
+      float n2 = 0;
+      for (int k = 0; k < 3; ++k) {
+        const float h = std::max(fabsf(e->h_shape_lmin[3 * sh + k]), fabsf(e->h_shape_lmax[3 * sh + k])) + 0.04f + e->d;
+        n2 += h * h;
+      }
+      discMax = std::max(discMax, 2.0f * sqrtf(n2));
+    }
+    SweepArgs sa;
+    NarrowArgs &a = sa.a;
+    memset(&a, 0, sizeof a);
+    a.sc = devScene(e); a.dm = dm; a.rb = devRobot(e); a.cp = cp;
+    a.dynXf0 = e->d_dynXf.p; a.dynXf1 = e->d_dynXf.p;
+    a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p; a.records = e->d_records.p;
+    sa.qchildren = d_qchildren; sa.nQ = nQ; sa.dynAabb0 = e->d_dynAabb.p;
+    sa.grow = 0.0011f + 4.0e-3f * discMax;
+    hipLaunchKernelGGL(k_sweep, dim3((unsigned)blocks), dim3(64), 0, s, sa);
+    HIPCHK(hipGetLastError());
+  }
+  for (int i = 3; i < NEV; ++i) HIPCHK(hipEventRecord(ev[i], s));   // the whole sweep is booked under "broadphase"
+  HIPCHK(hipEventRecord(ln.done, s));
+  tohc_engine::Pending pd;
+  pd.slot = slot;
+  pd.aabb_tests = 0;
+  e->pending.push_back(pd);
+  e->last_robot_mode = robotMode;
+  e->last_want_jac = false;
+  e->last_T = cp.T;
+  return TOHC_OK;
+}
+
 static int nextSlot(tohc_engine *e, int *slot) {
   if ((int)e->pending.size() >= RING) {
     int rc = syncEngine(e);
@@ -1029,6 +1083,86 @@ int tohc_links_vs_all_poses(tohc_engine *e, const double *obj_T, int n_sets, con
 int tohc_cast_vs_all_poses(tohc_engine *e, const double *obj_T, const double *cast_T1, int n_sets, const int32_t *query, int n_query,
                            const tohc_record **records, int *n_records) {
   return posesQuery(e, obj_T, cast_T1, n_sets, query, n_query, -1, 1, records, n_records);
+}
+
+int tohc_continuous_check_trajectory(tohc_engine *e, const double *dofs, int B, int T, const tohc_record **records, int *n_records) {
+  if (!e) return TOHC_E_INVALID;
+  if (!n_records) return fail(e, TOHC_E_INVALID, "n_records is null");
+  *n_records = 0;
+  if (records) *records = nullptr;
+  int rc = tohc_stage_dofs(e, dofs, B, T);
+  if (rc != TOHC_OK) return rc;
+  if (T < 2) return TOHC_OK;   // no segment
+  int slot;
+  rc = nextSlot(e, &slot);
+  if (rc != TOHC_OK) return rc;
+  const size_t n_sets = (size_t)B * T;
+  hipEvent_t *ev = &e->events[(size_t)slot * NEV];
+  DynMap dm = dynMapRobot(e);
+  hipStream_t s = e->stream;
+  for (auto &ln : e->lane) HIPCHK(hipStreamWaitEvent(s, ln.done, 0));
+  HIPCHK(hipEventRecord(ev[0], s));
+  hipLaunchKernelGGL(k_fk, dim3((unsigned)n_sets), dim3(64), (size_t)e->n_links * 7 * sizeof(double), s, devRobot(e), devScene(e), dm, e->d_dofs.p,
+                     (int)n_sets, e->d, e->d_linkQT.p, e->d_objQT.p, e->d_dynXf.p, e->d_dynAabb.p);
+  HIPCHK(hipEventRecord(ev[1], s));
+  HIPCHK(hipEventRecord(e->ev_fk, s));
+  e->fk_done = true;
+  CallParams cp;
+  memset(&cp, 0, sizeof cp);
+  cp.T = T; cp.gap = 1; cp.cast = 1; cp.filter_mask = TOHC_GROUP_KINBODY; cp.d = e->d; cp.breaking = e->breaking;
+  cp.unit_base = 0; cp.n_cast_sets = B * (T - 1);
+  e->last_sets = (int64_t)n_sets;
+  rc = launchSweep(e, dm, e->d_qchildrenR.p, e->h_qchildrenR, cp, true, slot);
+  if (rc != TOHC_OK) return rc;
+  const double *g = nullptr;
+  return tohc_fetch(e, records, &g, n_records);
+}
+
+int tohc_continuous_check_poses(tohc_engine *e, const double *obj_T, int n_steps, const int32_t *query, int n_query, const tohc_record **records,
+                                int *n_records) {
+  if (!e) return TOHC_E_INVALID;
+  if (!n_records) return fail(e, TOHC_E_INVALID, "n_records is null");
+  *n_records = 0;
+  if (records) *records = nullptr;
+  if (!e->have_scene) return fail(e, TOHC_E_STATE, "upload the scene first");
+  if (!obj_T || n_steps < 1 || n_query < 0 || (n_query > 0 && !query)) return fail(e, TOHC_E_INVALID, "null pose or query input");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(quiesce(e));
+  std::vector<int> qch;
+  for (int i = 0; i < n_query; ++i) {
+    int o = query[i];
+    if (o < 0 || o >= e->n_objects) return fail(e, TOHC_E_INVALID, "query object %d out of range", o);
+    for (int k = 0; k < e->h_obj_cnt[o]; ++k) qch.push_back(e->h_obj_off[o] + k);
+  }
+  if (n_steps < 2) return TOHC_OK;
+  int slot;
+  int rc = nextSlot(e, &slot);
+  if (rc != TOHC_OK) return rc;
+  e->staged = false;
+  hipStream_t s = e->stream;
+  hipEvent_t *ev = &e->events[(size_t)slot * NEV];
+  HIPCHK(hipEventRecord(ev[0], s));
+  HIPCHK(hipEventRecord(ev[1], s));
+  const size_t nobj = e->n_objects, nch = e->n_children;
+  HIPCHK(upload(e->d_objQT, obj_T, (size_t)n_steps * nobj * 7, s));
+  HIPCHK(upload(e->d_qchildrenP, qch, s));
+  HIPCHK(e->d_dynXf.reserve((size_t)n_steps * nch * 12)); HIPCHK(e->d_dynAabb.reserve((size_t)n_steps * nch * 6));
+  DynMap dm = dynMapPoses(e);
+  const size_t tot = (size_t)n_steps * nch;
+  hipLaunchKernelGGL(k_dyn_children, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, devScene(e), dm, e->d_objQT.p, n_steps, e->d, e->d_dynXf.p,
+                     e->d_dynAabb.p);
+  HIPCHK(hipEventRecord(e->ev_fk, s));
+  e->fk_done = false;
+  HIPCHK(hipStreamSynchronize(s));
+  CallParams cp;
+  memset(&cp, 0, sizeof cp);
+  cp.T = n_steps; cp.gap = 1; cp.cast = 1; cp.filter_mask = TOHC_GROUP_KINBODY; cp.d = e->d; cp.breaking = e->breaking;
+  cp.unit_base = 0; cp.n_cast_sets = n_steps - 1;
+  e->last_sets = n_steps;
+  rc = launchSweep(e, dm, e->d_qchildrenP.p, qch, cp, false, slot);
+  if (rc != TOHC_OK) return rc;
+  const double *g = nullptr;
+  return tohc_fetch(e, records, &g, n_records);
 }
 
 int tohc_forward_kinematics(tohc_engine *e, const double *dofs, int n_cfg, double *link_T) {

@@ -439,6 +439,154 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS) k_broadphase(CullArgs ca) {
   if (lane == 0 && ncand > 0) atomicAdd(&a.cnt->n_cand[shard], ncand);
 }
 
+// -----------------------------------------------------------------------------------------------------------------
+// k_sweep: ContinuousCheckTrajectory (bullet_collision_checker.cpp:683-753).  ONE WAVEFRONT per (trajectory segment,
+// swept geometry) = one convexSweepTest (btCollisionWorld.cpp:994-1056) with the ClosestConvexResultCallback:
+//   * cull: the box that holds the geometry at every pose of the interpolated motion (its box at the start rotation,
+//     grown by |angVel| * getAngularMotionDisc, swept along the origin's straight path) + `grow` (the 1 mm hit radius
+//     of calcTimeOfImpact, the jitter the advancement applies to the resting side, a guard band) against the cluster
+//     table / the moving children, like k_broadphase.  Bullet's own ray-vs-fattened-box cull is history dependent; both
+//     are conservative (while 3.001 d >= 1 mm), so the surviving hit is the same;
+//   * survivors are taken four at a time, one group of 16 lanes (a DPP row) each: hull vertices in registers,
+//     conservative advancement with the full pair detector per step (timeOfImpact<16>), EPA pools in LDS;
+//   * the closest hit wins (lowest fraction; ties -> lowest scene-wide child number, where the reference takes the
+//     first in DBVT order), written as one record: idA/childA the swept geometry, idB/childB what it hits, time =
+//     fraction, ptA = ptB = hit point, n = hit normal, dist = 0 (the arguments of the Collision the reference builds).
+// Filters: KinBodyFilter objects only, no allowed-pair matrix (ccc.m_collisionFilterMask, :688; ConvexResultCallback::
+// needsCollision does not consult it).
+// -----------------------------------------------------------------------------------------------------------------
+struct SweepArgs {
+  NarrowArgs a;
+  const int *qchildren;
+  int nQ;
+  const float *dynAabb0;
+  float grow;
+};
+__global__ void __launch_bounds__(64) k_sweep(SweepArgs sa) {
+  const NarrowArgs &a = sa.a;
+  const DevScene &sc = a.sc;
+  const DynMap &dm = a.dm;
+  const CallParams &cp = a.cp;
+  __shared__ EpaMem s_mem[4];
+  __shared__ int s_q[TOHC_BP_QCAP];
+  const int lane = threadIdx.x, grp = lane >> 4;
+  const int qi = blockIdx.x % sa.nQ;
+  const int cs = cp.unit_base + blockIdx.x / sa.nQ;
+  const int q = sa.qchildren[qi];
+  int set0, set1;
+  castSets(cp, cs, set0, set1);
+  const ChildDesc dq = sc.child_desc[q];
+  Cvx<16> cq;
+  Xf tf0;
+  loadSide<16>(a, q, dq, set0, set1, false, cq, tf0);
+  const Xf tf1 = childXf(a, a.dynXf1, set1, q);
+  const int shq = sc.child_shape[q];
+  const V3 qmin = mk(sc.shape_lmin[3 * shq], sc.shape_lmin[3 * shq + 1], sc.shape_lmin[3 * shq + 2]);
+  const V3 qmax = mk(sc.shape_lmax[3 * shq], sc.shape_lmax[3 * shq + 1], sc.shape_lmax[3 * shq + 2]);
+  const float discA = angularMotionDisc(dq.kind, mk(dq.dims[0], dq.dims[1], dq.dims[2]), qmin, qmax, cp.d);
+  Aabb bq;
+  {
+    V3 lin, ang;
+    calcVelocity(tf0, tf1, lin, ang);
+    Xf r0 = tf0;
+    r0.o = mk(0, 0, 0);
+    const Aabb b0 = shapeAabb(qmin, qmax, r0, 0.0f);
+    const float g = len(ang) * discA * 1.001f + sa.grow;
+    bq.lo = mk(fminf(tf0.o.x, tf1.o.x) + b0.lo.x - g, fminf(tf0.o.y, tf1.o.y) + b0.lo.y - g, fminf(tf0.o.z, tf1.o.z) + b0.lo.z - g);
+    bq.hi = mk(fmaxf(tf0.o.x, tf1.o.x) + b0.hi.x + g, fmaxf(tf0.o.y, tf1.o.y) + b0.hi.y + g, fmaxf(tf0.o.z, tf1.o.z) + b0.hi.z + g);
+  }
+  unsigned int nq = 0;   // wave-uniform
+  unsigned long long bestKey = ~0ull;
+  SweepOut best;
+  best.fraction = 0; best.normal = mk(0, 0, 0); best.point = mk(0, 0, 0);
+
+  auto drain = [&]() {
+    __syncthreads();   // one wavefront per block: orders the queue writes before the reads below
+    for (unsigned int k = grp; k < nq; k += 4) {
+      const int x = s_q[k];
+      const ChildDesc dx = sc.child_desc[x];
+      Cvx<16> cx;
+      Xf tx;
+      loadSide<16>(a, x, dx, set0, set1, false, cx, tx);
+      const int shx = sc.child_shape[x];
+      const float discB = angularMotionDisc(dx.kind, mk(dx.dims[0], dx.dims[1], dx.dims[2]), mk(sc.shape_lmin[3 * shx], sc.shape_lmin[3 * shx + 1], sc.shape_lmin[3 * shx + 2]),
+                                            mk(sc.shape_lmax[3 * shx], sc.shape_lmax[3 * shx + 1], sc.shape_lmax[3 * shx + 2]), cp.d);
+      SweepOut so;
+      if (timeOfImpact<16>(&s_mem[grp], cq, discA, tf0, tf1, cx, discB, tx, so)) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(so.fraction) << 32) | (unsigned int)x;
+        if (key < bestKey) { bestKey = key; best = so; }
+      }
+    }
+    __syncthreads();
+    nq = 0;
+  };
+  auto push = [&](bool hit, int x) {
+    if (hit) hit = (sc.obj_group[sc.child_obj[x]] & TOHC_GROUP_KINBODY) != 0;
+    const unsigned long long m = __ballot(hit);
+    if (hit) s_q[nq + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = x;
+    nq += (unsigned int)__popcll(m);
+    if (nq > TOHC_BP_QCAP - TOHC_BP_THREADS) drain();
+  };
+  for (int cb = 0; cb < dm.n_cl; cb += TOHC_BP_THREADS) {
+    const int c = cb + lane;
+    bool over = false;
+    if (c < dm.n_cl) {
+      const float *t = dm.cl_soa + c;
+      const int P = dm.n_cl_pad;
+      Aabb bc;
+      bc.lo = mk(t[0], t[P], t[2 * P]);
+      bc.hi = mk(t[3 * P], t[4 * P], t[5 * P]);
+      over = aabbOverlap(bq, bc);
+    }
+    unsigned long long cm = __ballot(over);
+    while (cm) {
+      const int cc = cb + (int)__builtin_ctzll(cm);
+      cm &= cm - 1;
+      const int i = cc * 64 + lane;
+      const float *t = dm.stat_soa + i;
+      const int P = dm.n_stat_pad;
+      Aabb bx;
+      bx.lo = mk(t[0], t[P], t[2 * P]);
+      bx.hi = mk(t[3 * P], t[4 * P], t[5 * P]);
+      const bool hit = aabbOverlap(bq, bx);
+      push(hit, hit ? dm.stat_children[i] : 0);
+    }
+  }
+  for (int base = 0; base < dm.n_dyn_children; base += TOHC_BP_THREADS) {
+    const int i = base + lane;
+    bool hit = false;
+    if (i < dm.n_dyn_children) hit = aabbOverlap(bq, ldAabb(sa.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + i) * 6));
+    push(hit, hit ? dm.dyn_children[i] : 0);
+  }
+  if (nq > 0) drain();
+  // the closest of the four groups' hits
+  unsigned long long k = bestKey;
+  for (int g = 0; g < 4; ++g) {
+    const unsigned long long o = __shfl(bestKey, g * 16);
+    k = o < k ? o : k;
+  }
+  if (k != ~0ull && k == bestKey && (lane & 15) == 0) {   // x is part of the key: exactly one group holds it
+    const unsigned int slot = atomicAdd(a.n_records, 1u);
+    if (slot < cp.max_records) {
+      const int x = (int)(unsigned int)(k & 0xffffffffull);
+      tohc_record r;
+      r.problem = set0 / cp.T;
+      r.t = set0 % cp.T;
+      r.idA = sc.child_obj[q]; r.childA = sc.child_idx[q]; r.idB = sc.child_obj[x]; r.childB = sc.child_idx[x];
+      r.cctype = TOHC_CC_NONE;
+      r.time = best.fraction;
+      r.dist = 0;
+      r.n[0] = best.normal.x; r.n[1] = best.normal.y; r.n[2] = best.normal.z;
+      r.ptA[0] = r.ptB[0] = best.point.x; r.ptA[1] = r.ptB[1] = best.point.y; r.ptA[2] = r.ptB[2] = best.point.z;
+      r.ptB1[0] = r.ptB1[1] = r.ptB1[2] = 0;
+      r.const0 = r.const1 = 0;
+      a.records[slot] = r;
+    } else {
+      a.cnt->overflow = 1;
+    }
+  }
+}
+
 // Bullet's output filter [gjk:430-449] + the collector's distance filter (bullet_collision_checker.cpp:401)
 template <int G>
 __device__ __forceinline__ void pushIfContact(const NarrowArgs &a, unsigned int pairPos, const GjkState &st, float md2) {

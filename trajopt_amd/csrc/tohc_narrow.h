@@ -1442,4 +1442,236 @@ TOHC_DEV void castClassify(const Cvx<G> &cq, const Xf &tf0, const Xf &tw1, V3 nW
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// ContinuousCheckTrajectory (bullet_collision_checker.cpp:683-753): time of impact of one swept convex geometry
+// against one resting geometry by conservative advancement,
+//   [ccc] .../NarrowPhaseCollision/btContinuousConvexCollision.cpp:49-241   [tu] LinearMath/btTransformUtil.h:20-140
+//   [cs2] .../CollisionShapes/btCollisionShape.cpp:32-58                    [m3] LinearMath/btMatrix3x3.h:448-478,1019-1029
+// fp32 in Bullet's operation order.  The reference calls libm's sinf / cosf / acosf here, and the advancement is
+// chaotically sensitive to their last bit (a 1-ulp change of one sine moves ~4 % of the fractions visibly: the pair
+// detector's degenerate-case branches are discontinuous).  glibc's routines cannot run on the device, so the device uses
+// the portable routines below; the CPU oracle and the host build of this file can switch to the same routines, which
+// makes GPU-vs-oracle parity bit-exact, while in libm mode they are bit-exact against the reference's Bullet.
+// ---------------------------------------------------------------------------------------------------------------
+/* Portable float sin / cos / acos: Taylor series in IEEE double (+, *, /, sqrt only, no contraction), rounded to float.
+ * The SAME operation sequence is compiled into the device code (tohc_narrow.h) and the CPU oracle (trajopt_oracle.c), so
+ * both produce identical bits; accuracy ~1e-16, i.e. the correctly rounded float in all but ~1e-8 of the cases.
+ * sin / cos are only called with |x| <= pi/8 (ANGULAR_MOTION_THRESHOLD, btTransformUtil.h:20,58-61). */
+TOHC_DEV double ptHorner(const double *c, int n, double x2) {
+  double r = c[n - 1];
+  for (int k = n - 2; k >= 0; --k) r = c[k] + x2 * r;
+  return r;
+}
+TOHC_DEV float ptSin(float xf) {
+  const double c[10] = {1.0, -0.16666666666666666, 0.008333333333333333, -0.0001984126984126984, 2.7557319223985893e-06, -2.505210838544172e-08, 1.6059043836821613e-10, -7.647163731819816e-13, 2.8114572543455206e-15, -8.22063524662433e-18};
+  const double x = (double)xf;
+  return (float)(x * ptHorner(c, 10, x * x));
+}
+TOHC_DEV float ptCos(float xf) {
+  const double c[10] = {1.0, -0.5, 0.041666666666666664, -0.001388888888888889, 2.48015873015873e-05, -2.755731922398589e-07, 2.08767569878681e-09, -1.1470745597729725e-11, 4.779477332387385e-14, -1.5619206968586225e-16};
+  const double x = (double)xf;
+  return (float)ptHorner(c, 10, x * x);
+}
+TOHC_DEV double ptAsinD(double z) { /* |z| <= ~0.71 */
+  const double c[30] = {1.0, 0.16666666666666666, 0.075, 0.044642857142857144, 0.030381944444444444, 0.022372159090909092, 0.017352764423076924, 0.01396484375, 0.011551800896139705, 0.009761609529194078, 0.008390335809616815, 0.0073125258735988454, 0.006447210311889649, 0.005740037670841924, 0.005153309682319905, 0.004660143486915096, 0.004240907093679363, 0.003880964558837669, 0.0035692053938259347, 0.003297059503473485, 0.0030578216492580306, 0.002846178401108942, 0.00265787063820729, 0.0024894486782468836, 0.002338091892111975, 0.0022014739737101384, 0.0020776610325181676, 0.0019650336162772837, 0.0018622264064031275, 0.0017680811205154183};
+  return z * ptHorner(c, 30, z * z);
+}
+TOHC_DEV float ptAcos(float xf) { /* xf in [-1, 1] */
+  const double PI = 3.141592653589793;
+  const double x = (double)xf;
+  if (x > 0.5) return (float)(2.0 * ptAsinD(sqrt((1.0 - x) * 0.5)));
+  if (x < -0.5) return (float)(PI - 2.0 * ptAsinD(sqrt((1.0 + x) * 0.5)));
+  return (float)(PI * 0.5 - ptAsinD(x));
+}
+#if defined(__HIPCC__)
+TOHC_DEV float libmSin(float x) { return ptSin(x); }
+TOHC_DEV float libmCos(float x) { return ptCos(x); }
+TOHC_DEV float libmAcos(float x) { return ptAcos(x); }
+#else
+// host build (tests/emu): 0 = libm's float routines, what the reference calls; 1 = the portable ones the device runs
+inline int &emuTrigMode() { static int m = 0; return m; }
+TOHC_DEV float libmSin(float x) { return emuTrigMode() ? ptSin(x) : sinf(x); }
+TOHC_DEV float libmCos(float x) { return emuTrigMode() ? ptCos(x) : cosf(x); }
+TOHC_DEV float libmAcos(float x) { return emuTrigMode() ? ptAcos(x) : acosf(x); }
+#endif
+struct Q4 { float x, y, z, w; };
+TOHC_DEV float m3el(const M3 &m, int i, int j) {
+  const V3 r = i == 0 ? m.r[0] : (i == 1 ? m.r[1] : m.r[2]);
+  return j == 0 ? r.x : (j == 1 ? r.y : r.z);
+}
+TOHC_DEV float cofac(const M3 &m, int r1, int c1, int r2, int c2) { return m3el(m, r1, c1) * m3el(m, r2, c2) - m3el(m, r1, c2) * m3el(m, r2, c1); }
+TOHC_DEV M3 m3Inverse(const M3 &m) {   // [m3:1019-1029]
+  V3 co = mk(cofac(m, 1, 1, 2, 2), cofac(m, 1, 2, 2, 0), cofac(m, 1, 0, 2, 1));
+  float det = dot(m.r[0], co);
+  float s = 1.0f / det;
+  M3 r;
+  r.r[0] = mk(co.x * s, cofac(m, 0, 2, 2, 1) * s, cofac(m, 0, 1, 1, 2) * s);
+  r.r[1] = mk(co.y * s, cofac(m, 0, 0, 2, 2) * s, cofac(m, 0, 2, 1, 0) * s);
+  r.r[2] = mk(co.z * s, cofac(m, 0, 1, 2, 0) * s, cofac(m, 0, 0, 1, 1) * s);
+  return r;
+}
+TOHC_DEV Q4 m3GetRotation(const M3 &m) {   // [m3:448-478], scalar branch
+  const float e00 = m.r[0].x, e11 = m.r[1].y, e22 = m.r[2].z;
+  float trace = e00 + e11 + e22;
+  Q4 q;
+  if (trace > 0.0f) {
+    float s = sqrtf(trace + 1.0f);
+    q.w = (s * 0.5f);
+    s = 0.5f / s;
+    q.x = ((m.r[2].y - m.r[1].z) * s);
+    q.y = ((m.r[0].z - m.r[2].x) * s);
+    q.z = ((m.r[1].x - m.r[0].y) * s);
+  } else {
+    const int i = e00 < e11 ? (e11 < e22 ? 2 : 1) : (e00 < e22 ? 2 : 0);
+    const int j = (i + 1) % 3, k = (i + 2) % 3;
+    float s = sqrtf(m3el(m, i, i) - m3el(m, j, j) - m3el(m, k, k) + 1.0f);
+    const float ti = s * 0.5f;
+    s = 0.5f / s;
+    const float tw = (m3el(m, k, j) - m3el(m, j, k)) * s;
+    const float tj = (m3el(m, j, i) + m3el(m, i, j)) * s;
+    const float tk = (m3el(m, k, i) + m3el(m, i, k)) * s;
+    q.w = tw;
+    q.x = i == 0 ? ti : (j == 0 ? tj : tk);
+    q.y = i == 1 ? ti : (j == 1 ? tj : tk);
+    q.z = i == 2 ? ti : (j == 2 ? tj : tk);
+  }
+  return q;
+}
+TOHC_DEV float q4len2(Q4 q) { return q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w; }
+TOHC_DEV Q4 q4normalize(Q4 q) {
+  const float s = 1.0f / sqrtf(q4len2(q));
+  Q4 r;
+  r.x = q.x * s; r.y = q.y * s; r.z = q.z * s; r.w = q.w * s;
+  return r;
+}
+TOHC_DEV Q4 q4mul(Q4 a, Q4 b) {
+  Q4 r;
+  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+  r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  return r;
+}
+TOHC_DEV M3 m3FromQuat(Q4 q) {   // btMatrix3x3::setRotation, scalar branch
+  const float d = q4len2(q);
+  const float s = 2.0f / d;
+  const float xs = q.x * s, ys = q.y * s, zs = q.z * s;
+  const float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
+  const float xx = q.x * xs, xy = q.x * ys, xz = q.x * zs;
+  const float yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
+  M3 r;
+  r.r[0] = mk(1.0f - (yy + zz), xy - wz, xz + wy);
+  r.r[1] = mk(xy + wz, 1.0f - (xx + zz), yz - wx);
+  r.r[2] = mk(xz - wy, yz + wx, 1.0f - (xx + yy));
+  return r;
+}
+// btTransformUtil::calculateVelocity with timeStep 1 [tu:108-139]
+TOHC_DEV void calcVelocity(const Xf &t0, const Xf &t1, V3 &linVel, V3 &angVel) {
+  linVel = vdiv(t1.o - t0.o, 1.0f);
+  const M3 dmat = mulMM(t1.b, m3Inverse(t0.b));
+  const Q4 dorn = q4normalize(m3GetRotation(dmat));
+  float w = dorn.w;
+  if (w < -1.0f) w = -1.0f;
+  if (w > 1.0f) w = 1.0f;
+  const float angle = 2.0f * libmAcos(w);
+  V3 axis = mk(dorn.x, dorn.y, dorn.z);
+  const float l2 = len2(axis);
+  if (l2 < FLT_EPSILON * FLT_EPSILON) axis = mk(1, 0, 0);
+  else axis = vdiv(axis, sqrtf(l2));
+  angVel = vdiv(axis * angle, 1.0f);
+}
+// btTransformUtil::integrateTransform [tu:42-78]
+TOHC_DEV Xf integrateTransform(const Xf &cur, V3 linvel, V3 angvel, float timeStep) {
+  const float AMT = 0.5f * (6.283185307179586232f * 0.25f);   // ANGULAR_MOTION_THRESHOLD
+  Xf out;
+  out.o = cur.o + linvel * timeStep;
+  V3 axis;
+  float fAngle = len(angvel);
+  if (fAngle * timeStep > AMT) fAngle = AMT / timeStep;
+  if (fAngle < 0.001f) axis = angvel * (0.5f * timeStep - (timeStep * timeStep * timeStep) * (0.020833333333f) * fAngle * fAngle);
+  else axis = angvel * (libmSin(0.5f * fAngle * timeStep) / fAngle);
+  Q4 dorn;
+  dorn.x = axis.x; dorn.y = axis.y; dorn.z = axis.z; dorn.w = libmCos(fAngle * timeStep * 0.5f);
+  const Q4 pred = q4normalize(q4mul(dorn, m3GetRotation(cur.b)));
+  out.b = m3FromQuat(pred);
+  return out;
+}
+// btCollisionShape::getAngularMotionDisc [cs2:32-58] over getAabb(identity): btTransformAabb with the patched
+// SHAPE_EXPANSION (= d); a hull's cached local box still carries the 0.04 construction margin
+TOHC_DEV float angularMotionDisc(int kind, V3 dims, V3 lmin, V3 lmax, float d) {
+  V3 mn, mx;
+  if (kind == KIND_HULL) {
+    const float CDM = 0.04f;
+    const V3 hi = mk(lmax.x + CDM, lmax.y + CDM, lmax.z + CDM), lo = mk(lmin.x - CDM, lmin.y - CDM, lmin.z - CDM);
+    V3 he = (hi - lo) * 0.5f;
+    he = he + (mk(0, 0, 0) + mk(d, d, d));
+    const V3 lc = (hi + lo) * 0.5f;
+    const V3 c = mk(1.0f * lc.x + 0.0f * lc.y + 0.0f * lc.z + 0.0f, 0.0f * lc.x + 1.0f * lc.y + 0.0f * lc.z + 0.0f, 0.0f * lc.x + 0.0f * lc.y + 1.0f * lc.z + 0.0f);
+    mn = c - he; mx = c + he;
+  } else {
+    const V3 he = (dims + mk(0, 0, 0)) + mk(d, d, d);
+    mn = mk(0, 0, 0) - he; mx = mk(0, 0, 0) + he;
+  }
+  const float radius = len(mx - mn) * 0.5f;
+  const V3 center = (mn + mx) * 0.5f;
+  return radius + len(center);
+}
+
+// computeClosestPoints [ccc:49-59]: the full pair detector (m_maximumDistanceSquared = BT_LARGE_FLOAT), both stages of
+// the penetration solver back to back on the group's EpaMem
+template <int G>
+TOHC_DEV void closestPoints(EpaMem *mem, const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &tB, PairOut &o) {
+  GjkState st;
+  gjkMain<G>(A, B, tA, tB, 1e18f, st);
+  if (st.needEpa) gjkFinishEpa<G>(mem, A, B, tA, tB, st);
+  gjkOutput(st, 1e18f, o);
+}
+struct SweepOut { float fraction; V3 normal, point; };
+// calcTimeOfImpact [ccc:90-241] with B at rest + the acceptance test of objectQuerySingleInternal
+// (btCollisionWorld.cpp:598-603, without the comparison against the closest hit so far); discA / discB: getAngularMotionDisc
+template <int G>
+TOHC_DEV bool timeOfImpact(EpaMem *mem, const Cvx<G> &A, float discA, const Xf &fromA, const Xf &toA, const Cvx<G> &B, float discB, const Xf &tB, SweepOut &out) {
+  V3 linVelA, angVelA, linVelB, angVelB;
+  calcVelocity(fromA, toA, linVelA, angVelA);
+  calcVelocity(tB, tB, linVelB, angVelB);
+  const float maxAngularProjectedVelocity = len(angVelA) * discA + len(angVelB) * discB;
+  const V3 relLinVel = linVelB - linVelA;
+  const float relLinVelocLength = len(linVelB - linVelA);
+  if ((relLinVelocLength + maxAngularProjectedVelocity) == 0.f) return false;
+  float lambda = 0.f, lastLambda = 0.f;
+  int numIter = 0;
+  const float radius = 0.001f;
+  PairOut o;
+  closestPoints<G>(mem, A, B, fromA, tB, o);
+  if (!o.valid) return false;
+  V3 c = o.pointOnB, n = o.normalOnB;
+  float dist = o.distance + 0.0f;
+  float projectedLinearVelocity = dot(relLinVel, n);
+  if ((projectedLinearVelocity + maxAngularProjectedVelocity) <= FLT_EPSILON) return false;
+  while (dist > radius) {
+    projectedLinearVelocity = dot(relLinVel, n);
+    if ((projectedLinearVelocity + maxAngularProjectedVelocity) <= FLT_EPSILON) return false;
+    const float dLambda = dist / (projectedLinearVelocity + maxAngularProjectedVelocity);
+    lambda = lambda + dLambda;
+    if (lambda > 1.0f) return false;
+    if (lambda < 0.0f) return false;
+    if (lambda <= lastLambda) return false;
+    lastLambda = lambda;
+    const Xf iA = integrateTransform(fromA, linVelA, angVelA, lambda);
+    const Xf iB = integrateTransform(tB, linVelB, angVelB, lambda);
+    closestPoints<G>(mem, A, B, iA, iB, o);
+    if (!o.valid) return false;
+    dist = o.distance + 0.0f;
+    c = o.pointOnB;
+    n = o.normalOnB;
+    numIter++;
+    if (numIter > 64) return false;
+  }
+  if (!(len2(n) > 0.0001f)) return false;
+  out.fraction = lambda;
+  out.normal = vdiv(n, len(n));   // castResult.m_normal.normalize()
+  out.point = c;
+  return true;
+}
+
 }  // namespace tohc

@@ -63,6 +63,8 @@ SYMBOLS = {
                                           C.POINTER(C.c_int)]),
     "tohc_cast_vs_all_poses": (C.c_int, [C.c_void_p, _f64p, _f64p, C.c_int, _i32p, C.c_int, C.POINTER(C.c_void_p),
                                          C.POINTER(C.c_int)]),
+    "tohc_continuous_check_trajectory": (C.c_int, [C.c_void_p, _f64p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
+    "tohc_continuous_check_poses": (C.c_int, [C.c_void_p, _f64p, C.c_int, _i32p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "tohc_forward_kinematics": (C.c_int, [C.c_void_p, _f64p, C.c_int, _f64p]),
     "tohc_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "tohc_set_capacity": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64]),
@@ -217,6 +219,22 @@ class Engine:
         rec, n = C.c_void_p(), C.c_int()
         self._chk(self.lib.tohc_cast_vs_all_poses(self.h, _p(obj_T, C.c_double), _p(T1, C.c_double), obj_T.shape[0],
                                                   _p(q, C.c_int32), len(q), C.byref(rec), C.byref(n)))
+        return self._collect(rec, None, n, 1, True)[0]
+
+    def continuous_check_trajectory(self, dofs, B, T):
+        """ContinuousCheckTrajectory for B trajectories of T waypoints -> records (time = hit fraction of segment t)"""
+        dofs = np.ascontiguousarray(dofs, np.float64)
+        assert dofs.size == B * T * self.K
+        rec, n = C.c_void_p(), C.c_int()
+        self._chk(self.lib.tohc_continuous_check_trajectory(self.h, _p(dofs, C.c_double), B, T, C.byref(rec), C.byref(n)))
+        return self._collect(rec, None, n, 1, True)[0]
+
+    def continuous_check_poses(self, obj_T, query):
+        obj_T = np.ascontiguousarray(obj_T, np.float64).reshape(-1, self.n_objects, 7)
+        q = np.ascontiguousarray(query, np.int32)
+        rec, n = C.c_void_p(), C.c_int()
+        self._chk(self.lib.tohc_continuous_check_poses(self.h, _p(obj_T, C.c_double), obj_T.shape[0], _p(q, C.c_int32), len(q),
+                                                       C.byref(rec), C.byref(n)))
         return self._collect(rec, None, n, 1, True)[0]
 
     def forward_kinematics(self, dofs):
