@@ -180,6 +180,13 @@ def main():
             lat.append((time.perf_counter() - tl) * 1e3)
         lat_ms = float(np.median(lat))
         lat_dev_ms = eng.counters()["ms_last_call"]
+        # ContinuousCheckTrajectory (the acceptance check of the reference's tests) of one problem, hits in host memory
+        sw = []
+        for _ in range(5):
+            tl = time.perf_counter()
+            n_sw = len(eng.continuous_check_trajectory(dofs[0], 1, T))
+            sw.append((time.perf_counter() - tl) * 1e3)
+        sweep_ms = float(np.median(sw))
 
     if rank == 0:
         launches = c1["cum_launches"] - c0["cum_launches"]
@@ -235,6 +242,8 @@ def main():
             "ms_per_sqp_linearization_single_problem_host_delivered": lat_ms,
             "ms_per_sqp_linearization_single_problem_device": lat_dev_ms,
             "api_value": api,
+            "ms_continuous_check_trajectory_single_problem": sweep_ms,
+            "continuous_check_hits_single_problem": n_sw,
             "kernel_ms_per_launch": ms,
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(dom),
