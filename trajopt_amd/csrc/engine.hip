@@ -67,7 +67,7 @@ struct tohc_engine {
   bool have_scene = false, have_robot = false;
   int n_shapes = 0, n_children = 0, n_objects = 0, n_verts = 0;
   std::vector<int> h_shape_kind, h_shape_voff, h_shape_vcnt, h_child_shape, h_child_obj, h_child_idx;
-  std::vector<float> h_shape_dims, h_shape_lmin, h_shape_lmax, h_child_localT;
+  std::vector<float> h_shape_dims, h_shape_lmin, h_shape_lmax, h_child_localT, h_shape_sph;
   std::vector<int> h_obj_off, h_obj_cnt, h_obj_compound, h_obj_group;
   std::vector<double> h_obj_static_T;
   std::vector<unsigned char> h_allowed;
@@ -287,7 +287,9 @@ static int refreshStatic(tohc_engine *e) {
       d.obj = obj; d.idx = e->h_child_idx[c]; d.kind = e->h_shape_kind[sh]; d.compound = e->h_obj_compound[obj];
       d.voff = e->h_shape_voff[sh]; d.vcnt = e->h_shape_vcnt[sh];
       d.dynR = e->h_child_dynR.empty() ? -1 : e->h_child_dynR[c];
+      d.group = e->h_obj_group[obj];
       for (int k = 0; k < 3; ++k) d.dims[k] = e->h_shape_dims[3 * sh + k];
+      for (int k = 0; k < 4; ++k) d.sph[k] = e->h_shape_sph[4 * sh + k];
     }
     HIPCHK(upload(e->d_child_desc, cd, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -400,6 +402,24 @@ int tohc_upload_scene(tohc_engine *e, int n_shapes, const int32_t *shape_kind, c
     } else {
       return fail(e, TOHC_E_UNSUPPORTED, "upload_scene: shape %d has kind %d; boxes, z-cylinders and convex hulls are supported (spheres: Bullet's sphere-specific algorithms are not restated)", i, shape_kind[i]);
     }
+  }
+  // bounding sphere of every shape about the centre of its local box (k_broadphase's first pre-test stage); the radius
+  // is rounded up so that the sphere certainly holds the shape
+  e->h_shape_sph.assign((size_t)n_shapes * 4, 0.f);
+  for (int i = 0; i < n_shapes; ++i) {
+    float c[3], r2 = 0;
+    for (int k = 0; k < 3; ++k) c[k] = 0.5f * (e->h_shape_lmin[3 * i + k] + e->h_shape_lmax[3 * i + k]);
+    if (shape_kind[i] == TOHC_HULL) {
+      for (int k = 0; k < e->h_shape_vcnt[i]; ++k) {
+        const int v = e->h_shape_voff[i] + k;
+        const double dx = (double)vx[v] - c[0], dy = (double)vy[v] - c[1], dz = (double)vz[v] - c[2];
+        r2 = std::max(r2, (float)(dx * dx + dy * dy + dz * dz));
+      }
+    } else {   // box / cylinder: the corner of the local box
+      for (int k = 0; k < 3; ++k) { const double h = (double)e->h_shape_lmax[3 * i + k] - c[k]; r2 += (float)(h * h); }
+    }
+    for (int k = 0; k < 3; ++k) e->h_shape_sph[4 * i + k] = c[k];
+    e->h_shape_sph[4 * i + 3] = sqrtf(r2) * 1.00001f + 1.0e-6f;
   }
   e->h_child_shape.assign(child_shape, child_shape + n_children);
   e->h_child_obj.assign(n_children, -1); e->h_child_idx.assign(n_children, 0);
@@ -744,6 +764,7 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
     ca.a = a; ca.qchildren = d_qchildren; ca.nQ = nQ;
     ca.dynAabb0 = e->d_dynAabb.p; ca.dynAabb1 = sep1 ? e->d_dynAabb1.p : e->d_dynAabb.p;
     ca.pretest = e->pretest;
+    ca.dbg = getenv("TOHC_BP_DBG") ? atoi(getenv("TOHC_BP_DBG")) : 0;
     if (cp.cast) hipLaunchKernelGGL((k_broadphase<true>), dim3((unsigned)blocks), dim3(TOHC_BP_THREADS), 0, s, ca);
     else hipLaunchKernelGGL((k_broadphase<false>), dim3((unsigned)blocks), dim3(TOHC_BP_THREADS), 0, s, ca);
     HIPCHK(hipEventRecord(ev[3], s));

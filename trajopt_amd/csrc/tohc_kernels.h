@@ -23,13 +23,14 @@ namespace tohc {
 
 #define TOHC_NSHARD 16
 
-struct ChildDesc {   // 48 B, one 16-B-aligned record per child: cuts the dependent-load chain of the pair set-up to
+struct ChildDesc {   // 64 B = one cache line per child: cuts the dependent-load chain of the pair set-up to
   int obj, idx;      // pair -> desc -> vertices
   int kind, compound;
   int voff, vcnt;
-  int dynR, pad;     // slot among the robot's moving children (robot mode) or -1
+  int dynR, group;   // slot among the robot's moving children (robot mode) or -1; the object's filter group
   float dims[3];
   float pad2;
+  float sph[4];      // bounding sphere in the child's frame: centre of its local box, radius (slightly inflated)
 };
 struct DevScene {
   int n_shapes, n_children, n_objects;
@@ -71,7 +72,10 @@ struct PairRec { int set, q, x, pad; };
 struct EpaRec { int pair; int isValid; float distance; float n[3]; float pB[3]; };
 struct HitRec { int pair; float distance; float n[3]; float pB[3]; };
 struct PenRec { EpaRec e; PenHand h; };   // k_pen -> k_epa
-#define TOHC_EPA_WAVES 2                   // k_epa is bound by the latency of dependent instructions: more resident waves, more pairs in flight
+#ifndef TOHC_EPA_WAVES
+#define TOHC_EPA_WAVES 2
+#endif
+//                                         k_epa is bound by the latency of dependent instructions: more resident waves, more pairs in flight
 #define TOHC_PEN_DIV 8                     // the k_pen -> k_epa queue holds 1/8 of the pair capacity
 struct Counters {  // one per enqueue
   unsigned int n_pairs[TOHC_NSHARD], n_epa[TOHC_NSHARD], n_hits[TOHC_NSHARD];
@@ -319,9 +323,13 @@ struct CullArgs {
   int nQ;
   const float *dynAabb0, *dynAabb1;
   int pretest;
+  int dbg;   // timing experiments only (TOHC_BP_DBG): 1 = count the box-test survivors and drop them, 2 = stage 1 only, drop the rest
 };
 template <bool CAST>
-__global__ void __launch_bounds__(TOHC_BP_THREADS) k_broadphase(CullArgs ca) {
+#ifndef TOHC_BP_WAVES
+#define TOHC_BP_WAVES 1
+#endif
+__global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(CullArgs ca) {
   const NarrowArgs &a = ca.a;
   const DevScene &sc = a.sc;
   const DynMap &dm = a.dm;
@@ -345,10 +353,11 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS) k_broadphase(CullArgs ca) {
   Cvx<1> cq;
   Xf tq;
 
-  // pre-test the queued box-test survivors, one lane per pair, and append what is left to the pair list
+  // The queued box-test survivors, one lane per pair: object-level filters (here and not in the scan loop: they are
+  // three dependent loads, which per overlapping cluster made the scan a chain of ~100 L2 round trips per wavefront),
+  // pre-test, and what is left goes to the pair list.
   auto drain = [&]() {
     __syncthreads();   // one wavefront per block: orders the queue writes before the reads below
-    ncand += nq;
     if (ca.pretest && !haveQ) {
       loadSide<1>(a, q, sc.child_desc[q], set0, set1, CAST, cq, tq);
       haveQ = true;
@@ -357,15 +366,38 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS) k_broadphase(CullArgs ca) {
       const unsigned int k = k0 + lane;
       bool keep = k < nq;
       int x = 0;
+      ChildDesc dx;
       if (keep) {
         x = s_q[k];
-        if (ca.pretest) {
-          Cvx<1> cx;
-          Xf tx;
-          loadSide<1>(a, x, sc.child_desc[x], set0, set1, false, cx, tx);
-          const V3 dir = tq.o - tx.o;
-          V3 w;
-          keep = !((len2(dir) > 1.0e-12f) && sepAxisBeyond<1>(cq, cx, tq, tx, dir, lim, w));
+        dx = sc.child_desc[x];
+        const int X = dx.obj, gx = dx.group;
+        keep = (X != Q) && (CAST ? (gx & TOHC_GROUP_KINBODY) != 0 : (gx & (short)cp.filter_mask) != 0)  // cast: KinBodyFilter (bcc:983)
+               && allowedRow[X] != 0;
+      }
+      ncand += (unsigned int)__popcll(__ballot(keep));
+      if (ca.dbg == 1) keep = false;
+      if (keep && ca.pretest) {
+        // one direction for both stages: from the other child's bounding-sphere centre to the query's origin.
+        // Stage 1 needs nothing of the other child but its descriptor (one cache line) and pose: the query's support
+        // point against the SPHERE bounds the distance from below; ~94 % of what the exact test rejects ends here.
+        // Stage 2 (the exact support of the other child, a scan of its vertices) only runs for the rest.
+        const Xf tx = childXf(a, a.dynXf0, set0, x);
+        const V3 c = xfApply(tx, mk(dx.sph[0], dx.sph[1], dx.sph[2]));
+        const V3 dir = tq.o - c;
+        const float dl2 = len2(dir);
+        if (dl2 > 1.0e-12f) {
+          const float dl = sqrtf(dl2);
+          const V3 pA = xfApply(tq, supNV<1>(cq, mulVM(-dir, tq.b)));
+          const float deltaS = dot(dir, pA - c) - dx.sph[3] * dl;
+          if ((deltaS > 0.0f && deltaS > lim * dl) || ca.dbg == 2) {
+            keep = false;
+          } else {
+            Cvx<1> cx;
+            cvxLoad<1>(cx, dx.kind, mk(dx.dims[0], dx.dims[1], dx.dims[2]), sc.vx, sc.vy, sc.vz, sc.v4, dx.voff, dx.vcnt);
+            const V3 qB = xfApply(tx, supNV<1>(cx, mulVM(dir, tx.b)));
+            const float delta = dot(dir, pA - qB);
+            keep = !((delta > 0.0f) && (delta * delta > (lim * lim) * dl2));
+          }
         }
       }
       const unsigned long long m = __ballot(keep);
@@ -390,12 +422,6 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS) k_broadphase(CullArgs ca) {
     nq = 0;
   };
   auto push = [&](bool hit, int x) {
-    if (hit) {  // object-level filters, only for boxes that overlap
-      const int X = sc.child_obj[x];
-      const int gx = sc.obj_group[X];
-      hit = (X != Q) && (CAST ? (gx & TOHC_GROUP_KINBODY) != 0 : (gx & (short)cp.filter_mask) != 0)  // cast: KinBodyFilter (bcc:983)
-            && allowedRow[X] != 0;
-    }
     const unsigned long long m = __ballot(hit);
     if (hit) s_q[nq + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = x;
     nq += (unsigned int)__popcll(m);
@@ -415,25 +441,50 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS) k_broadphase(CullArgs ca) {
       over = aabbOverlap(bq, bc);
     }
     unsigned long long cm = __ballot(over);
+    // four clusters per round, all their loads (boxes and child numbers) issued before the first test: the loop is a
+    // chain of L2 round trips otherwise (one per overlapping cluster, two with the child number loaded after the test)
     while (cm) {
-      const int cc = cb + (int)__builtin_ctzll(cm);
-      cm &= cm - 1;
-      const int i = cc * 64 + lane;           // pad entries hold inverted boxes: they never overlap
-      const float *t = dm.stat_soa + i;
+      int cc[4];
+      float bb[4][6];
+      int ch[4];
       const int P = dm.n_stat_pad;
-      Aabb bx;
-      bx.lo = mk(t[0], t[P], t[2 * P]);
-      bx.hi = mk(t[3 * P], t[4 * P], t[5 * P]);
-      const bool hit = aabbOverlap(bq, bx);
-      push(hit, hit ? dm.stat_children[i] : 0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        cc[u] = -1;
+        if (cm) { cc[u] = cb + (int)__builtin_ctzll(cm); cm &= cm - 1; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (cc[u] >= 0) {
+          const int i = cc[u] * 64 + lane;       // pad entries hold inverted boxes: they never overlap
+          const float *t = dm.stat_soa + i;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) bb[u][k] = t[k * P];
+          ch[u] = dm.stat_children[i];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (cc[u] >= 0) {
+          Aabb bx;
+          bx.lo = mk(bb[u][0], bb[u][1], bb[u][2]);
+          bx.hi = mk(bb[u][3], bb[u][4], bb[u][5]);
+          const bool hit = aabbOverlap(bq, bx);
+          push(hit, hit ? ch[u] : 0);
+        }
+      }
     }
   }
   // moving children
   for (int base = 0; base < dm.n_dyn_children; base += TOHC_BP_THREADS) {
     const int i = base + lane;
     bool hit = false;
-    if (i < dm.n_dyn_children) hit = aabbOverlap(bq, ldAabb(ca.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + i) * 6));
-    push(hit, hit ? dm.dyn_children[i] : 0);
+    int chx = 0;
+    if (i < dm.n_dyn_children) {
+      chx = dm.dyn_children[i];
+      hit = aabbOverlap(bq, ldAabb(ca.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + i) * 6));
+    }
+    push(hit, chx);
   }
   if (nq > 0) drain();
   if (lane == 0 && ncand > 0) atomicAdd(&a.cnt->n_cand[shard], ncand);
@@ -505,6 +556,7 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs sa) {
     for (unsigned int k = grp; k < nq; k += 4) {
       const int x = s_q[k];
       const ChildDesc dx = sc.child_desc[x];
+      if (!(dx.group & TOHC_GROUP_KINBODY)) continue;   // ccc.m_collisionFilterMask = KinBodyFilter (bcc:688)
       Cvx<16> cx;
       Xf tx;
       loadSide<16>(a, x, dx, set0, set1, false, cx, tx);
@@ -521,7 +573,6 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs sa) {
     nq = 0;
   };
   auto push = [&](bool hit, int x) {
-    if (hit) hit = (sc.obj_group[sc.child_obj[x]] & TOHC_GROUP_KINBODY) != 0;
     const unsigned long long m = __ballot(hit);
     if (hit) s_q[nq + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = x;
     nq += (unsigned int)__popcll(m);
@@ -548,15 +599,20 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs sa) {
       Aabb bx;
       bx.lo = mk(t[0], t[P], t[2 * P]);
       bx.hi = mk(t[3 * P], t[4 * P], t[5 * P]);
+      const int chx = dm.stat_children[i];
       const bool hit = aabbOverlap(bq, bx);
-      push(hit, hit ? dm.stat_children[i] : 0);
+      push(hit, chx);
     }
   }
   for (int base = 0; base < dm.n_dyn_children; base += TOHC_BP_THREADS) {
     const int i = base + lane;
     bool hit = false;
-    if (i < dm.n_dyn_children) hit = aabbOverlap(bq, ldAabb(sa.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + i) * 6));
-    push(hit, hit ? dm.dyn_children[i] : 0);
+    int chx = 0;
+    if (i < dm.n_dyn_children) {
+      chx = dm.dyn_children[i];
+      hit = aabbOverlap(bq, ldAabb(sa.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + i) * 6));
+    }
+    push(hit, chx);
   }
   if (nq > 0) drain();
   // the closest of the four groups' hits
@@ -615,7 +671,10 @@ __device__ __forceinline__ void pushIfContact(const NarrowArgs &a, unsigned int 
 // is usually unchanged and only the other side is reloaded.
 #define TOHC_RUN 8
 template <int G, bool CAST, int BLOCK>
-__global__ void __launch_bounds__(BLOCK, 2) k_gjk(NarrowArgs a) {
+#ifndef TOHC_GJK_WAVES
+#define TOHC_GJK_WAVES 2
+#endif
+__global__ void __launch_bounds__(BLOCK, TOHC_GJK_WAVES) k_gjk(NarrowArgs a) {
   const int groupsPerBlock = BLOCK / G;
   const unsigned int gid = blockIdx.x * groupsPerBlock + threadIdx.x / G;
   const unsigned int ngroups = gridDim.x * groupsPerBlock;
@@ -719,7 +778,10 @@ __device__ __forceinline__ void loadQueued(const NarrowArgs &a, const EpaRec &e,
 // difference go on to k_epa with that state (PenRec); for the rest the Distance fall-back runs here and the pair is
 // finished.
 template <bool CAST>
-__global__ void __launch_bounds__(64, 2) k_pen(NarrowArgs a) {
+#ifndef TOHC_PEN_WAVES
+#define TOHC_PEN_WAVES 2
+#endif
+__global__ void __launch_bounds__(64, TOHC_PEN_WAVES) k_pen(NarrowArgs a) {
   __shared__ G2Mem mem[64];
   const unsigned int gid = blockIdx.x * 64 + threadIdx.x;
   const unsigned int nlanes = gridDim.x * 64;

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libtrajopt_hipcc.so")
+LIB_PATH = os.environ.get("TOHC_LIB") or os.path.join(HERE, "libtrajopt_hipcc.so")   # TOHC_LIB: experiment builds (scripts/)
 
 RECORD_DTYPE = np.dtype([
     ("problem", "i4"), ("t", "i4"), ("idA", "i4"), ("childA", "i4"), ("idB", "i4"), ("childB", "i4"),
