@@ -653,7 +653,8 @@ static int syncEngine(tohc_engine *e) {
   hipStream_t s = e->stream;
   for (auto &ln : e->lane) HIPCHK(hipStreamSynchronize(ln.stream));
   if (e->pending.empty()) { HIPCHK(hipStreamSynchronize(s)); return TOHC_OK; }
-  HIPCHK(hipMemcpyAsync(e->h_cnt.p, e->d_cnt.p, sizeof(Counters) * RING, hipMemcpyDeviceToHost, s));
+  for (const auto &pd : e->pending)   // only the slots in use: a Counters is 2 KB now
+    HIPCHK(hipMemcpyAsync(e->h_cnt.p + pd.slot, e->d_cnt.p + pd.slot, sizeof(Counters), hipMemcpyDeviceToHost, s));
   HIPCHK(hipMemcpyAsync(e->h_nrec.p, e->d_nrec.p, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   bool overflow = false;
@@ -667,8 +668,9 @@ static int syncEngine(tohc_engine *e) {
     unsigned int np = 0, ne = 0, ng = 0;
     overflow |= k.overflow != 0;
     for (int sh = 0; sh < TOHC_NSHARD; ++sh) {
-      overflow |= k.n_pairs[sh] > segCap || k.n_epa[sh] > segCap || k.n_hits[sh] > segCap || k.n_pen[sh] > segCap / TOHC_PEN_DIV;
-      np += k.n_cand[sh]; ng += k.n_pairs[sh]; ne += k.n_epa[sh];
+      const CounterShard &cs = k.sh[sh];
+      overflow |= cs.n_pairs > segCap || cs.n_epa > segCap || cs.n_hits > segCap || cs.n_pen > segCap / TOHC_PEN_DIV;
+      np += cs.n_cand; ng += cs.n_pairs; ne += cs.n_epa;
     }
     worst_pairs = std::max(worst_pairs, ng);
     c.aabb_tests += pd.aabb_tests; c.pair_evals += np; c.epa_evals += ne; c.gjk_evals += ng;

@@ -77,12 +77,20 @@ struct PenRec { EpaRec e; PenHand h; };   // k_pen -> k_epa
 #endif
 //                                         k_epa is bound by the latency of dependent instructions: more resident waves, more pairs in flight
 #define TOHC_PEN_DIV 8                     // the k_pen -> k_epa queue holds 1/8 of the pair capacity
-struct Counters {  // one per enqueue
-  unsigned int n_pairs[TOHC_NSHARD], n_epa[TOHC_NSHARD], n_hits[TOHC_NSHARD];
-  unsigned int n_pen[TOHC_NSHARD];   // pairs k_pen hands to k_epa (origin inside the Minkowski difference)
-  unsigned int n_cand[TOHC_NSHARD];  // box-test survivors = pair evaluations; n_pairs = those the pre-test passes on to k_gjk
-  unsigned int overflow, pad[15];
+// One per enqueue.  Every shard of the queue counters sits on its own 128-byte line: atomics on words of ONE line
+// serialise (~88 per microsecond, MI355X_MICROARCH "dequeue"), so 16 shards inside one line were no shards at all --
+// the per-wavefront adds of k_broadphase's discrete pass alone cost ~200 us that way.
+struct CounterShard {
+  unsigned int n_pairs, n_epa, n_hits;
+  unsigned int n_pen;    // pairs k_pen hands to k_epa (origin inside the Minkowski difference)
+  unsigned int n_cand;   // box-test survivors = pair evaluations; n_pairs = those the pre-test passes on to k_gjk
+  unsigned int pad[27];
 };
+struct Counters {
+  CounterShard sh[TOHC_NSHARD];
+  unsigned int overflow, pad[31];
+};
+#define TOHC_CNT_STRIDE (sizeof(CounterShard) / sizeof(unsigned int))
 
 struct CallParams {
   int n_cast_sets;   // number of (problem, t) units enumerated by this launch ...
@@ -130,7 +138,7 @@ __device__ __forceinline__ void qprefix(const unsigned int *counts, unsigned int
 #pragma unroll
   for (int i = 0; i < TOHC_NSHARD; ++i) {
     p.start[i] = acc;
-    unsigned int c = counts[i];
+    unsigned int c = counts[i * TOHC_CNT_STRIDE];
     acc += c < segCap ? c : segCap;
   }
   p.start[TOHC_NSHARD] = acc;
@@ -404,7 +412,7 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
       const unsigned int cnt = (unsigned int)__popcll(m);
       if (cnt > 0) {
         unsigned int base = 0;
-        if (lane == 0) base = atomicAdd(&a.cnt->n_pairs[shard], cnt);
+        if (lane == 0) base = atomicAdd(&a.cnt->sh[shard].n_pairs, cnt);
         base = __shfl(base, 0);
         if (keep) {
           const unsigned int pos = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
@@ -429,7 +437,7 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
   };
 
   // children that never move: cluster boxes first, then the members of the clusters that overlap
-  for (int cb = 0; cb < dm.n_cl; cb += TOHC_BP_THREADS) {
+  for (int cb = 0; cb < (ca.dbg == 3 ? 0 : dm.n_cl); cb += TOHC_BP_THREADS) {
     const int c = cb + lane;
     bool over = false;
     if (c < dm.n_cl) {
@@ -476,7 +484,7 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
     }
   }
   // moving children
-  for (int base = 0; base < dm.n_dyn_children; base += TOHC_BP_THREADS) {
+  for (int base = 0; base < (ca.dbg == 4 ? 0 : dm.n_dyn_children); base += TOHC_BP_THREADS) {
     const int i = base + lane;
     bool hit = false;
     int chx = 0;
@@ -487,7 +495,7 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
     push(hit, chx);
   }
   if (nq > 0) drain();
-  if (lane == 0 && ncand > 0) atomicAdd(&a.cnt->n_cand[shard], ncand);
+  if (lane == 0 && ncand > 0) atomicAdd(&a.cnt->sh[shard].n_cand, ncand);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -652,7 +660,7 @@ __device__ __forceinline__ void pushIfContact(const NarrowArgs &a, unsigned int 
   if ((double)o.distance > (double)a.cp.d) return;
   if (Grp<G>::lane() == 0) {
     const int shard = blockIdx.x % TOHC_NSHARD;
-    unsigned int slot = atomicAdd(&a.cnt->n_hits[shard], 1u);
+    unsigned int slot = atomicAdd(&a.cnt->sh[shard].n_hits, 1u);
     if (slot < a.cp.seg_cap) {
       HitRec h;
       h.pair = (int)pairPos;
@@ -679,7 +687,7 @@ __global__ void __launch_bounds__(BLOCK, TOHC_GJK_WAVES) k_gjk(NarrowArgs a) {
   const unsigned int gid = blockIdx.x * groupsPerBlock + threadIdx.x / G;
   const unsigned int ngroups = gridDim.x * groupsPerBlock;
   QPrefix pre;
-  qprefix(a.cnt->n_pairs, a.cp.seg_cap, pre);
+  qprefix(&a.cnt->sh[0].n_pairs, a.cp.seg_cap, pre);
   const unsigned int npairs = pre.start[TOHC_NSHARD];
   float md2 = a.cp.breaking;
   md2 *= md2;  // (marginA + marginB + gContactBreakingThreshold)^2 with zero margins [cca:370-373]
@@ -730,7 +738,7 @@ __global__ void __launch_bounds__(BLOCK, TOHC_GJK_WAVES) k_gjk(NarrowArgs a) {
       if (st.needEpa) {
         if (Grp<G>::lane() == 0) {
           const int shard = blockIdx.x % TOHC_NSHARD;
-          unsigned int slot = atomicAdd(&a.cnt->n_epa[shard], 1u);
+          unsigned int slot = atomicAdd(&a.cnt->sh[shard].n_epa, 1u);
           if (slot < a.cp.seg_cap) {
             EpaRec e;
             e.pair = (int)pos;
@@ -786,7 +794,7 @@ __global__ void __launch_bounds__(64, TOHC_PEN_WAVES) k_pen(NarrowArgs a) {
   const unsigned int gid = blockIdx.x * 64 + threadIdx.x;
   const unsigned int nlanes = gridDim.x * 64;
   QPrefix pre;
-  qprefix(a.cnt->n_epa, a.cp.seg_cap, pre);
+  qprefix(&a.cnt->sh[0].n_epa, a.cp.seg_cap, pre);
   const unsigned int nepa = pre.start[TOHC_NSHARD];
   float md2 = a.cp.breaking;
   md2 *= md2;
@@ -803,7 +811,7 @@ __global__ void __launch_bounds__(64, TOHC_PEN_WAVES) k_pen(NarrowArgs a) {
     Gjk2<1, G2Mem> g;
     if (penStage1<1, G2Mem>(&mem[threadIdx.x], A, B, lA, lB, g, isValid2, sep, tmpA, tmpB)) {
       const int shard = blockIdx.x % TOHC_NSHARD;
-      const unsigned int slot = atomicAdd(&a.cnt->n_pen[shard], 1u);
+      const unsigned int slot = atomicAdd(&a.cnt->sh[shard].n_pen, 1u);
       if (slot < cap2) {
         PenRec *r = &a.penq[(size_t)shard * cap2 + slot];
         r->e = e;
@@ -827,7 +835,7 @@ __global__ void __launch_bounds__(BLOCK, TOHC_EPA_WAVES) k_epa(NarrowArgs a) {
   const unsigned int ngroups = gridDim.x * groupsPerBlock;
   const unsigned int cap2 = a.cp.seg_cap / TOHC_PEN_DIV;
   QPrefix pre;
-  qprefix(a.cnt->n_pen, cap2, pre);
+  qprefix(&a.cnt->sh[0].n_pen, cap2, pre);
   const unsigned int npen = pre.start[TOHC_NSHARD];
   EpaMem *m = &mem[threadIdx.x / G];
   float md2 = a.cp.breaking;
@@ -992,7 +1000,7 @@ __global__ void __launch_bounds__(256) k_finish(NarrowArgs a) {
   const unsigned int gid = blockIdx.x * groupsPerBlock + threadIdx.x / G;
   const unsigned int ngroups = gridDim.x * groupsPerBlock;
   QPrefix pre;
-  qprefix(a.cnt->n_hits, a.cp.seg_cap, pre);
+  qprefix(&a.cnt->sh[0].n_hits, a.cp.seg_cap, pre);
   const unsigned int nhits = pre.start[TOHC_NSHARD];
   const unsigned int base = *a.n_records;
   const int gl = Grp<G>::lane();
@@ -1070,7 +1078,7 @@ __global__ void __launch_bounds__(256) k_finish(NarrowArgs a) {
 // after k_finish: the slab now holds base + hits records
 __global__ void k_bump(Counters *cnt, unsigned int segCap, unsigned int *n_records) {
   QPrefix pre;
-  qprefix(cnt->n_hits, segCap, pre);
+  qprefix(&cnt->sh[0].n_hits, segCap, pre);
   *n_records += pre.start[TOHC_NSHARD];
 }
 
