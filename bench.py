@@ -39,7 +39,7 @@ def build_world(rank, world, problems, T=100):
     cc = CC.HIPCollisionChecker(s, static_T, None, device=rank_device(rank))
     cc.SetRobot(rb)                       # uploads + IgnoreZeroStateSelfCollisions, like the reference's AddKinBody path
     cc.SetContactDistance(d)
-    cc.eng.set_capacity(1 << 23, 1 << 21)
+    cc.eng.set_capacity(max(1 << 23, problems * (1 << 16)), max(1 << 21, problems * 40000))   # ~30 K GJK pairs / 25 K records per problem and step
     lo, hi = multi_gpu.partition(problems * world, world, rank)
     dofs = np.stack([synth.fullbody_trajectory(rb, np.random.default_rng(1000 + g), T) for g in range(lo, hi)])
     return s, rb, static_T, d, cc, dofs
@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--problems-per-gpu", type=int, default=8)
+    ap.add_argument("--problems-per-gpu", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -155,6 +155,19 @@ def main():
     pair_evals = c1["cum_pair_evals"] - c0["cum_pair_evals"]
     from trajopt_amd import multi_gpu
     dt_max, pairs_all = multi_gpu.reduce_measurement(dt, pair_evals, dist, device="cuda")
+
+    # The north-star's one exchange step, AFTER the path and outside `value`: every rank's result slab of one step to
+    # every rank (RCCL all-gather over xGMI; padded fixed-size slabs), so a single SQP host can read all of them.
+    gather_ms = gather_bytes = None
+    if dist is not None:
+        multi_gpu.all_gather_slabs(rec[:1024], grads[:1024], dist, device="cuda")   # warm-up (communicator set-up)
+        barrier()
+        tg = time.perf_counter()
+        recs_all, _ = multi_gpu.all_gather_slabs(rec, grads, dist, device="cuda")
+        barrier()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        gather_bytes = int(sum(len(r) for r in recs_all) * (152 + 16 * rb.K))
+        assert len(recs_all) == world and len(recs_all[rank]) == len(rec)
 
     # PCIe-inclusive API rate on rank 0's data (never `value`)
     api = None
@@ -242,6 +255,7 @@ def main():
             "ms_per_sqp_linearization_single_problem_host_delivered": lat_ms,
             "ms_per_sqp_linearization_single_problem_device": lat_dev_ms,
             "api_value": api,
+            "allgather_slabs_ms": gather_ms, "allgather_slabs_bytes": gather_bytes,
             "ms_continuous_check_trajectory_single_problem": sweep_ms,
             "continuous_check_hits_single_problem": n_sw,
             "kernel_ms_per_launch": ms,

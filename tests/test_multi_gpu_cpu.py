@@ -1,7 +1,8 @@
 """N > 1 path on the CPU: two `gloo` ranks shard a set of multi-start problems (trajopt_amd/multi_gpu.py), each rank
 linearizes its own block -- with the CPU oracle standing in for the GPU engine, this is a test -- and the union must
 equal the single-process result; the scalar reductions of the bench contract (max time, summed units) are checked too.
-There is no data-path collective to test: the ranks never exchange contacts."""
+Computing needs no collective; the optional exchange step after it (all_gather_slabs: every rank's slab on every rank,
+the north-star's "all-gather of linearizations") is checked bit for bit as well."""
 import os
 import socket
 import sys
@@ -55,7 +56,15 @@ def _rank_main(rank, world, port, q):
         dist.barrier()
         tmax, usum = multi_gpu.reduce_measurement(1.0 + rank, pe, dist)
         counts = multi_gpu.gather_counts(len(mine), dist)
-        q.put((rank, lo, hi, mine, pe, tmax, usum, counts.tolist()))
+        # the optional exchange step: every rank's slab on every rank (ragged counts, padded messages)
+        from trajopt_amd import engine
+        rec = np.zeros(len(mine), engine.RECORD_DTYPE)
+        rec["problem"] = [m[0] for m in mine]; rec["cctype"] = [m[1] for m in mine]; rec["t"] = [m[2] for m in mine]
+        rec["dist"] = [m[7] for m in mine]
+        grads = np.stack([np.frombuffer(m[8], np.float64) for m in mine]).reshape(len(mine), 2, -1)
+        recs, gs = multi_gpu.all_gather_slabs(rec, grads, dist)
+        gathered = [(r["problem"].tolist(), r["dist"].tolist(), g.tobytes()) for r, g in zip(recs, gs)]
+        q.put((rank, lo, hi, mine, pe, tmax, usum, counts.tolist(), gathered))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -102,3 +111,8 @@ def test_two_gloo_ranks_shard_the_problems():
     for g in got:
         assert g[5] == 2.0 and g[6] == float(pe_ref)                # max over ranks of the time, sum of the units
         assert g[7] == [len(got[0][3]), len(got[1][3])]
+        # all_gather_slabs: both ranks hold both slabs, bit for bit, in rank order
+        for r in range(2):
+            src = got[r][3]
+            assert g[8][r][0] == [m[0] for m in src] and g[8][r][1] == [m[7] for m in src]
+            assert g[8][r][2] == b"".join(m[8] for m in src)

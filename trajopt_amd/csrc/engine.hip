@@ -143,6 +143,7 @@ struct tohc_engine {
   bool last_robot_mode = true, last_want_jac = false;
   size_t fetched_n = 0;
   int gjk_group = 1;  // lanes per pair in k_gjk: 1 (default), 16 or 64 (TOHC_GJK_GROUP)
+  int pen_group = 1;   // lanes per pair in k_pen: 1, or 4 (hull vertices in registers; TOHC_PEN_GROUP=4: measured no faster, GJK2's LDS bookkeeping dominates)
   int epa_block = 64;  // threads per k_epa block (TOHC_EPA_BLOCK = 16 or 64)
   int pretest = 1;   // TOHC_PRETEST=0 turns the separating-axis pre-test off (A/B measurements)
   tohc_engine() { memset(&counters, 0, sizeof counters); }
@@ -216,6 +217,7 @@ int tohc_create(tohc_engine **out, int device) {
       return TOHC_E_HIP;
     }
   if (const char *eb = getenv("TOHC_EPA_BLOCK")) e->epa_block = atoi(eb) == 16 ? 16 : 64;
+  if (const char *pg = getenv("TOHC_PEN_GROUP")) e->pen_group = atoi(pg) == 4 ? 4 : 1;
   if (const char *hs = getenv("TOHC_HOST_SORT")) e->host_sort = atoi(hs) != 0;
   e->gjk_group = e->group == 64 ? 64 : 1;
   if (const char *gg = getenv("TOHC_GJK_GROUP")) { int v = atoi(gg); if (v == 1 || v == 16 || v == 64) e->gjk_group = v; }
@@ -782,8 +784,13 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
       else hipLaunchKernelGGL((k_gjk<16, false, 256>), dim3(gridN), dim3(256), 0, s, a);
     }
     HIPCHK(hipEventRecord(ev[4], s));
-    if (cp.cast) hipLaunchKernelGGL((k_pen<true>), dim3(gridN), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((k_pen<false>), dim3(gridN), dim3(64), 0, s, a);
+    if (e->pen_group == 4) {
+      if (cp.cast) hipLaunchKernelGGL((k_pen<true, 4>), dim3(gridN), dim3(64), 0, s, a);
+      else hipLaunchKernelGGL((k_pen<false, 4>), dim3(gridN), dim3(64), 0, s, a);
+    } else {
+      if (cp.cast) hipLaunchKernelGGL((k_pen<true, 1>), dim3(gridN), dim3(64), 0, s, a);
+      else hipLaunchKernelGGL((k_pen<false, 1>), dim3(gridN), dim3(64), 0, s, a);
+    }
     if (e->group == 64) hipLaunchKernelGGL((k_epa<64, 64>), dim3(gridN), dim3(64), 0, s, a);
     else if (e->epa_block == 16) hipLaunchKernelGGL((k_epa<16, 16>), dim3(gridN * 4), dim3(16), 0, s, a);  // one group per wavefront
     else hipLaunchKernelGGL((k_epa<16, 64>), dim3(gridN), dim3(64), 0, s, a);

@@ -584,45 +584,57 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs sa) {
     const unsigned long long m = __ballot(hit);
     if (hit) s_q[nq + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = x;
     nq += (unsigned int)__popcll(m);
-    if (nq > TOHC_BP_QCAP - TOHC_BP_THREADS) drain();
   };
-  for (int cb = 0; cb < dm.n_cl; cb += TOHC_BP_THREADS) {
-    const int c = cb + lane;
-    bool over = false;
-    if (c < dm.n_cl) {
-      const float *t = dm.cl_soa + c;
-      const int P = dm.n_cl_pad;
-      Aabb bc;
-      bc.lo = mk(t[0], t[P], t[2 * P]);
-      bc.hi = mk(t[3 * P], t[4 * P], t[5 * P]);
-      over = aabbOverlap(bq, bc);
+  // The scan is a producer with ONE consumer call site: fill the queue, drain, repeat.  (With drain() called from
+  // several places the compiler keeps it as a function, and everything it captures -- both hulls, the poses, the
+  // best hit -- then lives in scratch memory: 1.1 KB per lane, 330 MB of HBM writes per launch.)
+  int stage = dm.n_cl > 0 ? 0 : 1;   // 0: clusters of the table, 1: moving children, 2: done
+  int cb = -TOHC_BP_THREADS, base = 0;
+  unsigned long long cm = 0;
+  while (stage < 2 || nq > 0) {
+    while (stage < 2 && nq <= TOHC_BP_QCAP - TOHC_BP_THREADS) {
+      if (stage == 0) {
+        if (cm == 0) {   // next block of 64 cluster boxes
+          cb += TOHC_BP_THREADS;
+          if (cb >= dm.n_cl) { stage = 1; continue; }
+          const int c = cb + lane;
+          bool over = false;
+          if (c < dm.n_cl) {
+            const float *t = dm.cl_soa + c;
+            const int P = dm.n_cl_pad;
+            Aabb bc;
+            bc.lo = mk(t[0], t[P], t[2 * P]);
+            bc.hi = mk(t[3 * P], t[4 * P], t[5 * P]);
+            over = aabbOverlap(bq, bc);
+          }
+          cm = __ballot(over);
+          continue;
+        }
+        const int cc = cb + (int)__builtin_ctzll(cm);
+        cm &= cm - 1;
+        const int i = cc * 64 + lane;
+        const float *t = dm.stat_soa + i;
+        const int P = dm.n_stat_pad;
+        Aabb bx;
+        bx.lo = mk(t[0], t[P], t[2 * P]);
+        bx.hi = mk(t[3 * P], t[4 * P], t[5 * P]);
+        const int chx = dm.stat_children[i];
+        push(aabbOverlap(bq, bx), chx);
+      } else {
+        if (base >= dm.n_dyn_children) { stage = 2; continue; }
+        const int i = base + lane;
+        bool hit = false;
+        int chx = 0;
+        if (i < dm.n_dyn_children) {
+          chx = dm.dyn_children[i];
+          hit = aabbOverlap(bq, ldAabb(sa.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + i) * 6));
+        }
+        push(hit, chx);
+        base += TOHC_BP_THREADS;
+      }
     }
-    unsigned long long cm = __ballot(over);
-    while (cm) {
-      const int cc = cb + (int)__builtin_ctzll(cm);
-      cm &= cm - 1;
-      const int i = cc * 64 + lane;
-      const float *t = dm.stat_soa + i;
-      const int P = dm.n_stat_pad;
-      Aabb bx;
-      bx.lo = mk(t[0], t[P], t[2 * P]);
-      bx.hi = mk(t[3 * P], t[4 * P], t[5 * P]);
-      const int chx = dm.stat_children[i];
-      const bool hit = aabbOverlap(bq, bx);
-      push(hit, chx);
-    }
+    drain();
   }
-  for (int base = 0; base < dm.n_dyn_children; base += TOHC_BP_THREADS) {
-    const int i = base + lane;
-    bool hit = false;
-    int chx = 0;
-    if (i < dm.n_dyn_children) {
-      chx = dm.dyn_children[i];
-      hit = aabbOverlap(bq, ldAabb(sa.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + i) * 6));
-    }
-    push(hit, chx);
-  }
-  if (nq > 0) drain();
   // the closest of the four groups' hits
   unsigned long long k = bestKey;
   for (int g = 0; g < 4; ++g) {
@@ -651,26 +663,49 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs sa) {
   }
 }
 
+// One queue slot for every lane that wants one, with ONE atomic per wavefront: the lanes that are active here vote,
+// the first of them reserves for all.  Call it with all lanes of a (possibly divergent) branch, `want` false for the
+// lanes that only take part in the vote.  Blocks of the lane-per-pair kernels are single wavefronts.
+__device__ __forceinline__ unsigned int waveSlot(unsigned int *ctr, bool want) {
+  const unsigned long long m = __ballot(want);
+  unsigned int slot = 0;
+  if (want) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int leader = (int)__builtin_ctzll(m);
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(ctr, (unsigned int)__popcll(m));
+    base = __shfl(base, leader);
+    slot = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+  }
+  return slot;
+}
 // Bullet's output filter [gjk:430-449] + the collector's distance filter (bullet_collision_checker.cpp:401)
+__device__ __forceinline__ bool isContact(const NarrowArgs &a, const GjkState &st, float md2, PairOut &o) {
+  gjkOutput(st, md2, o);
+  return o.valid && !((double)o.distance > (double)a.cp.d);
+}
+__device__ __forceinline__ void writeHit(const NarrowArgs &a, int shard, unsigned int slot, unsigned int pairPos, const PairOut &o) {
+  if (slot < a.cp.seg_cap) {
+    HitRec h;
+    h.pair = (int)pairPos;
+    h.distance = o.distance;
+    h.n[0] = o.normalOnB.x; h.n[1] = o.normalOnB.y; h.n[2] = o.normalOnB.z;
+    h.pB[0] = o.pointOnB.x; h.pB[1] = o.pointOnB.y; h.pB[2] = o.pointOnB.z;
+    a.hits[(size_t)shard * a.cp.seg_cap + slot] = h;
+  } else {
+    a.cnt->overflow = 1;
+  }
+}
 template <int G>
 __device__ __forceinline__ void pushIfContact(const NarrowArgs &a, unsigned int pairPos, const GjkState &st, float md2) {
   PairOut o;
-  gjkOutput(st, md2, o);
-  if (!o.valid) return;
-  if ((double)o.distance > (double)a.cp.d) return;
-  if (Grp<G>::lane() == 0) {
-    const int shard = blockIdx.x % TOHC_NSHARD;
-    unsigned int slot = atomicAdd(&a.cnt->sh[shard].n_hits, 1u);
-    if (slot < a.cp.seg_cap) {
-      HitRec h;
-      h.pair = (int)pairPos;
-      h.distance = o.distance;
-      h.n[0] = o.normalOnB.x; h.n[1] = o.normalOnB.y; h.n[2] = o.normalOnB.z;
-      h.pB[0] = o.pointOnB.x; h.pB[1] = o.pointOnB.y; h.pB[2] = o.pointOnB.z;
-      a.hits[(size_t)shard * a.cp.seg_cap + slot] = h;
-    } else {
-      a.cnt->overflow = 1;
-    }
+  const bool hit = isContact(a, st, md2, o);
+  const int shard = blockIdx.x % TOHC_NSHARD;
+  if (G == 1) {
+    const unsigned int slot = waveSlot(&a.cnt->sh[shard].n_hits, hit);
+    if (hit) writeHit(a, shard, slot, pairPos, o);
+  } else if (hit && Grp<G>::lane() == 0) {
+    writeHit(a, shard, atomicAdd(&a.cnt->sh[shard].n_hits, 1u), pairPos, o);
   }
 }
 
@@ -735,25 +770,29 @@ __global__ void __launch_bounds__(BLOCK, TOHC_GJK_WAVES) k_gjk(NarrowArgs a) {
       GjkState st;
       g.finish(st);
       active = false;
-      if (st.needEpa) {
-        if (Grp<G>::lane() == 0) {
-          const int shard = blockIdx.x % TOHC_NSHARD;
-          unsigned int slot = atomicAdd(&a.cnt->sh[shard].n_epa, 1u);
-          if (slot < a.cp.seg_cap) {
-            EpaRec e;
-            e.pair = (int)pos;
-            e.isValid = st.isValid;
-            e.distance = st.distance;
-            e.n[0] = st.normalInB.x; e.n[1] = st.normalInB.y; e.n[2] = st.normalInB.z;
-            e.pB[0] = st.pointOnB.x; e.pB[1] = st.pointOnB.y; e.pB[2] = st.pointOnB.z;
-            a.epaq[(size_t)shard * a.cp.seg_cap + slot] = e;
-          } else {
-            a.cnt->overflow = 1;
-          }
+      const int shard = blockIdx.x % TOHC_NSHARD;
+      unsigned int slot = 0;
+      bool writeE = st.needEpa;
+      if (G == 1) slot = waveSlot(&a.cnt->sh[shard].n_epa, st.needEpa);
+      else if (st.needEpa && Grp<G>::lane() == 0) slot = atomicAdd(&a.cnt->sh[shard].n_epa, 1u);
+      else writeE = false;
+      if (writeE) {
+        if (slot < a.cp.seg_cap) {
+          EpaRec e;
+          e.pair = (int)pos;
+          e.isValid = st.isValid;
+          e.distance = st.distance;
+          e.n[0] = st.normalInB.x; e.n[1] = st.normalInB.y; e.n[2] = st.normalInB.z;
+          e.pB[0] = st.pointOnB.x; e.pB[1] = st.pointOnB.y; e.pB[2] = st.pointOnB.z;
+          a.epaq[(size_t)shard * a.cp.seg_cap + slot] = e;
+        } else {
+          a.cnt->overflow = 1;
         }
-      } else {
-        pushIfContact<G>(a, pos, st, md2);
       }
+      // (every lane that finished in this step takes part in the vote inside; pairs on their way to EPA are no contact yet)
+      GjkState sh = st;
+      if (st.needEpa) sh.isValid = false;
+      pushIfContact<G>(a, pos, sh, md2);
     }
   }
 }
@@ -781,18 +820,19 @@ __device__ __forceinline__ void loadQueued(const NarrowArgs &a, const EpaRec &e,
   st.iters = 0;
 }
 
-// k_pen: first stage of calcPenDepth for the pairs k_gjk queued, ONE LANE per pair: GJK2 needs only four support
-// vertices, so its whole state fits a 140-byte LDS record per lane.  Pairs whose origin lies inside the Minkowski
-// difference go on to k_epa with that state (PenRec); for the rest the Distance fall-back runs here and the pair is
-// finished.
-template <bool CAST>
+// k_pen: first stage of calcPenDepth for the pairs k_gjk queued, a group of G lanes per pair (G = 4: the two hulls sit in
+// the group's registers, 16 vertices a lane, so a support query is 16 dot products and two DPP steps instead of a
+// scan through L2; G = 1: one lane per pair, hulls read from memory).  GJK2 needs only four support vertices, so its
+// whole state fits a 140-byte LDS record per group.  Pairs whose origin lies inside the Minkowski difference go on to
+// k_epa with that state (PenRec); for the rest the Distance fall-back runs here and the pair is finished.
 #ifndef TOHC_PEN_WAVES
 #define TOHC_PEN_WAVES 2
 #endif
+template <bool CAST, int G>
 __global__ void __launch_bounds__(64, TOHC_PEN_WAVES) k_pen(NarrowArgs a) {
-  __shared__ G2Mem mem[64];
-  const unsigned int gid = blockIdx.x * 64 + threadIdx.x;
-  const unsigned int nlanes = gridDim.x * 64;
+  __shared__ G2Mem mem[64 / G];
+  const unsigned int gid = (blockIdx.x * 64 + threadIdx.x) / G;
+  const unsigned int nlanes = gridDim.x * 64 / G;
   QPrefix pre;
   qprefix(&a.cnt->sh[0].n_epa, a.cp.seg_cap, pre);
   const unsigned int nepa = pre.start[TOHC_NSHARD];
@@ -801,28 +841,33 @@ __global__ void __launch_bounds__(64, TOHC_PEN_WAVES) k_pen(NarrowArgs a) {
   const unsigned int cap2 = a.cp.seg_cap / TOHC_PEN_DIV;
   for (unsigned int i = gid; i < nepa; i += nlanes) {
     const EpaRec e = a.epaq[qlocate(pre, a.cp.seg_cap, i)];
-    Cvx<1> A, B;
+    Cvx<G> A, B;
     Xf tA, tB, lA, lB;
     GjkState st;
-    loadQueued<1>(a, e, CAST, A, B, tA, tB, st);
+    loadQueued<G>(a, e, CAST, A, B, tA, tB, st);
     penLocal(tA, tB, st.offset, lA, lB);
     V3 tmpA = mk(0, 0, 0), tmpB = mk(0, 0, 0), sep = mk(0, 0, 0);
     bool isValid2 = false;
-    Gjk2<1, G2Mem> g;
-    if (penStage1<1, G2Mem>(&mem[threadIdx.x], A, B, lA, lB, g, isValid2, sep, tmpA, tmpB)) {
-      const int shard = blockIdx.x % TOHC_NSHARD;
-      const unsigned int slot = atomicAdd(&a.cnt->sh[shard].n_pen, 1u);
+    Gjk2<G, G2Mem> g;
+    const bool toEpa = penStage1<G, G2Mem>(&mem[threadIdx.x / G], A, B, lA, lB, g, isValid2, sep, tmpA, tmpB);
+    const int shard = blockIdx.x % TOHC_NSHARD;
+    unsigned int slot = 0;
+    bool writeP = toEpa;
+    if (G == 1) slot = waveSlot(&a.cnt->sh[shard].n_pen, toEpa);
+    else if (toEpa && Grp<G>::lane() == 0) slot = atomicAdd(&a.cnt->sh[shard].n_pen, 1u);
+    else writeP = false;
+    if (writeP) {
       if (slot < cap2) {
         PenRec *r = &a.penq[(size_t)shard * cap2 + slot];
         r->e = e;
-        penSave<1, G2Mem>(r->h, g);
+        penSave<G, G2Mem>(r->h, g);
       } else {
         a.cnt->overflow = 1;
       }
-    } else {
-      gjkFinishTail(isValid2, sep, tmpA, tmpB, st);
-      pushIfContact<1>(a, (unsigned int)e.pair, st, md2);
     }
+    if (toEpa) st.isValid = false;   // no contact yet: k_epa decides
+    else gjkFinishTail(isValid2, sep, tmpA, tmpB, st);
+    pushIfContact<G>(a, (unsigned int)e.pair, st, md2);
   }
 }
 

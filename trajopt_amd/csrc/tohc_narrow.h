@@ -45,10 +45,10 @@ struct Grp {
     combine(v, i, ov, oi);
   }
   static TOHC_DEV void argmax(float &v, int &i) {
-    dppStep<0xB1>(v, i);   // quad_perm [1,0,3,2]
-    dppStep<0x4E>(v, i);   // quad_perm [2,3,0,1]
-    dppStep<0x141>(v, i);  // row_half_mirror
-    dppStep<0x140>(v, i);  // row_mirror
+    if (G >= 2) dppStep<0xB1>(v, i);    // quad_perm [1,0,3,2]
+    if (G >= 4) dppStep<0x4E>(v, i);    // quad_perm [2,3,0,1]
+    if (G >= 8) dppStep<0x141>(v, i);   // row_half_mirror
+    if (G >= 16) dppStep<0x140>(v, i);  // row_mirror
 #pragma unroll
     for (int m = 16; m < G; m <<= 1) combine(v, i, __shfl_xor(v, m, G), __shfl_xor(i, m, G));
   }
@@ -66,10 +66,10 @@ struct Grp {
     combineHi(v, i, ov, oi);
   }
   static TOHC_DEV void argmax_hi(float &v, int &i) {
-    dppStepHi<0xB1>(v, i);
-    dppStepHi<0x4E>(v, i);
-    dppStepHi<0x141>(v, i);
-    dppStepHi<0x140>(v, i);
+    if (G >= 2) dppStepHi<0xB1>(v, i);
+    if (G >= 4) dppStepHi<0x4E>(v, i);
+    if (G >= 8) dppStepHi<0x141>(v, i);
+    if (G >= 16) dppStepHi<0x140>(v, i);
 #pragma unroll
     for (int m = 16; m < G; m <<= 1) combineHi(v, i, __shfl_xor(v, m, G), __shfl_xor(i, m, G));
   }
@@ -112,7 +112,7 @@ struct Cvx<1> {
 };
 
 template <int G>
-TOHC_DEV void cvxLoad(Cvx<G> &c, int kind, V3 dims, const float *vx, const float *vy, const float *vz, const F4 *, int voff, int n) {
+TOHC_DEV void cvxLoad(Cvx<G> &c, int kind, V3 dims, const float *vx, const float *vy, const float *vz, const F4 *v4, int voff, int n) {
   c.kind = kind;
   c.cast = 0;
   c.n = n;
@@ -122,9 +122,16 @@ TOHC_DEV void cvxLoad(Cvx<G> &c, int kind, V3 dims, const float *vx, const float
   for (int s = 0; s < Cvx<G>::VPL; ++s) {
     int i = s * G + gl;
     bool in = (kind == KIND_HULL) && (i < n);
-    c.x[s] = in ? vx[voff + i] : 0.0f;
-    c.y[s] = in ? vy[voff + i] : 0.0f;
-    c.z[s] = in ? vz[voff + i] : 0.0f;
+    if (G >= 16) {   // SoA: the group's lanes read consecutive floats
+      c.x[s] = in ? vx[voff + i] : 0.0f;
+      c.y[s] = in ? vy[voff + i] : 0.0f;
+      c.z[s] = in ? vz[voff + i] : 0.0f;
+    } else {         // small groups: one 16-byte record per vertex (G consecutive records = G*16 contiguous bytes)
+      F4 p;
+      p.x = p.y = p.z = p.w = 0.0f;
+      if (in) p = v4[voff + i];
+      c.x[s] = p.x; c.y[s] = p.y; c.z[s] = p.z;
+    }
   }
 }
 
@@ -1377,6 +1384,29 @@ TOHC_DEV void gjkOutput(const GjkState &st, float maxDist2, PairOut &o) {
 // vertices serially in index order with a running maximum, which is order dependent; the group replays exactly that
 // scan: vertex i is broadcast from its owning lane in index order (only for kept contacts, so the cost is small).
 // ---------------------------------------------------------------------------------------------------------------
+struct AvgAcc { V3 sum; float cnt, maxS; };
+TOHC_DEV void avgStep(AvgAcc &a, V3 pt, V3 nl) {
+  const float EPS = 1e-3f;
+  float sup = dot(pt, nl);
+  if (sup > a.maxS + EPS) { a.cnt = 1; a.sum = pt; a.maxS = sup; }
+  else if (sup < a.maxS - EPS) {}
+  else { a.cnt += 1; a.sum = a.sum + pt; }
+}
+// hull vertices in index order; the register slots are indexed by compile-time constants only (a dynamic slot index
+// sends the whole vertex array through scratch memory: 80 bytes per LANE and hit, 650 MB per launch of k_finish)
+template <int G>
+TOHC_DEV void avgHull(const Cvx<G> &c, V3 nl, AvgAcc &a) {
+#pragma unroll
+  for (int s = 0; s < Cvx<G>::VPL; ++s) {
+    if (s * G >= c.n) break;
+    const int lim = c.n - s * G < G ? c.n - s * G : G;
+    for (int src = 0; src < lim; ++src) avgStep(a, mk(Grp<G>::bcast(c.x[s], src), Grp<G>::bcast(c.y[s], src), Grp<G>::bcast(c.z[s], src)), nl);
+  }
+}
+template <>
+TOHC_DEV void avgHull<1>(const Cvx<1> &c, V3 nl, AvgAcc &a) {
+  for (int i = 0; i < c.n; ++i) avgStep(a, cvxVertex<1>(c, i), nl);
+}
 template <int G>
 TOHC_DEV void averageSupport(const Cvx<G> &c, V3 nl, float &outsup, V3 &outpt) {
   if (c.kind == KIND_CYLZ) {  // not polyhedral: the support vertex itself [bcc:124-129]
@@ -1384,26 +1414,18 @@ TOHC_DEV void averageSupport(const Cvx<G> &c, V3 nl, float &outsup, V3 &outpt) {
     outsup = dot(nl, outpt);
     return;
   }
-  V3 sum = mk(0, 0, 0);
-  float cnt = 0, maxS = -1000;
-  const float EPS = 1e-3f;
-  const int np = c.kind == KIND_BOX ? 8 : c.n;
-  for (int i = 0; i < np; ++i) {
-    V3 pt;
-    if (c.kind == KIND_BOX) {
-      V3 he = c.dims;
-      pt = mk(he.x * (1 - (i & 1)) - he.x * (i & 1), he.y * (1 - ((i & 2) >> 1)) - he.y * ((i & 2) >> 1),
-              he.z * (1 - ((i & 4) >> 2)) - he.z * ((i & 4) >> 2));
-    } else {
-      pt = cvxVertex<G>(c, i);
-    }
-    float sup = dot(pt, nl);
-    if (sup > maxS + EPS) { cnt = 1; sum = pt; maxS = sup; }
-    else if (sup < maxS - EPS) {}
-    else { cnt += 1; sum = sum + pt; }
+  AvgAcc a;
+  a.sum = mk(0, 0, 0); a.cnt = 0; a.maxS = -1000;
+  if (c.kind == KIND_BOX) {
+    const V3 he = c.dims;
+    for (int i = 0; i < 8; ++i)
+      avgStep(a, mk(he.x * (1 - (i & 1)) - he.x * (i & 1), he.y * (1 - ((i & 2) >> 1)) - he.y * ((i & 2) >> 1),
+                    he.z * (1 - ((i & 4) >> 2)) - he.z * ((i & 4) >> 2)), nl);
+  } else {
+    avgHull<G>(c, nl, a);
   }
-  outsup = maxS;
-  outpt = vdiv(sum, cnt);
+  outsup = a.maxS;
+  outpt = vdiv(a.sum, a.cnt);
 }
 
 // CastCollisionCollector::addSingleResult [bcc:894-972].  In: the contact as Bullet reported it (A/B = GJK roles,

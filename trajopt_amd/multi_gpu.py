@@ -1,8 +1,10 @@
 """Multi-GPU layout of the linearization path: one process per GPU, independent problems (multi-start trajectories,
-BASELINE.json configs[4]) partitioned over the ranks.  The data path has NO collective -- a rank's contacts and
-gradient rows belong to its own problems; the only exchanges are the barrier and the scalar reductions of the
-measurement (max wall time, summed pair evaluations).  Works on any torch.distributed backend: `nccl` (= RCCL over
-xGMI) on the GPUs, `gloo` in the CPU tests.
+BASELINE.json configs[4]) partitioned over the ranks.  Computing the linearizations needs NO collective -- a rank's
+contacts and gradient rows belong to its own problems; the exchanges of the measurement are the barrier and two scalar
+reductions (max wall time, summed pair evaluations).  The one real exchange step of the north-star is optional and
+comes AFTER the path: `all_gather_slabs` returns every rank's result slab to every rank (so that a single SQP host can
+read all of them from one GPU) with one all-gather of the record counts and one all-gather of fixed-size padded slabs.
+Works on any torch.distributed backend: `nccl` (= RCCL over xGMI) on the GPUs, `gloo` in the CPU tests.
 """
 import numpy as np
 
@@ -45,3 +47,36 @@ def global_problem_ids(records, lo):
     out = records.copy()
     out["problem"] += lo
     return out
+
+
+def all_gather_slabs(records, grads, dist=None, device="cpu"):
+    """Every rank's (records, grads) on every rank, in rank order, problems renumbered job-wide by the caller.
+    records: numpy structured array [n] (engine.RECORD_DTYPE, 152 B); grads: float64 [n, 2, K] or None.
+    One all-gather of the counts, then ONE all-gather of a byte slab padded to the largest count (fixed-size messages:
+    over xGMI every rank pushes its slab to its 7 peers on 7 distinct links).  Returns (list of records per rank,
+    list of grads per rank)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [records], [grads]
+    import torch
+    world = dist.get_world_size()
+    counts = gather_counts(len(records), dist, device)
+    nmax = int(counts.max())
+    rec_b = records.dtype.itemsize
+    g_b = 0 if grads is None else int(np.prod(grads.shape[1:])) * 8
+    row = rec_b + g_b
+    buf = np.zeros((max(nmax, 1), row), np.uint8)
+    n = len(records)
+    if n:
+        buf[:n, :rec_b] = np.ascontiguousarray(records).view(np.uint8).reshape(n, rec_b)
+        if g_b:
+            buf[:n, rec_b:] = np.ascontiguousarray(grads, np.float64).view(np.uint8).reshape(n, g_b)
+    mine = torch.from_numpy(buf).to(device)
+    out = torch.empty((world * mine.shape[0], mine.shape[1]), dtype=torch.uint8, device=device)   # rank-major concatenation
+    dist.all_gather_into_tensor(out, mine)
+    host = out.cpu().numpy().reshape(world, mine.shape[0], mine.shape[1])
+    recs, gs = [], []
+    for r in range(world):
+        c = int(counts[r])
+        recs.append(np.ascontiguousarray(host[r, :c, :rec_b]).view(records.dtype).reshape(c))
+        gs.append(None if not g_b else np.ascontiguousarray(host[r, :c, rec_b:]).view(np.float64).reshape((c,) + tuple(grads.shape[1:])))
+    return recs, gs
