@@ -66,3 +66,39 @@ def assert_same_linearization(rec, grads, orec, ograds, tag="", exact_values=Tru
         k0 = np.abs(rec["const0"] - orec["const0"]).max()
         k1 = np.abs(rec["const1"] - orec["const1"]).max()
         assert max(k0, k1) <= jac_rtol * scale * 10, "%s: constants differ by %g" % (tag, max(k0, k1))
+
+
+def write_flat_world(path, scene, rb, static_T, traj, d, dist_pen, coeff):
+    """A scene + robot + trajectory as named arrays of numbers, the input of tests/cpp/host_unit (`linearize`).
+    Values are printed with repr(), so doubles and fp32 values survive the text round trip bit for bit."""
+    a, r = scene.arrays, rb.arrays
+    items = {k: a[k] for k in ("kind", "param", "voff", "vcnt", "verts", "child_shape", "child_T", "obj_off", "obj_cnt", "obj_compound", "obj_group")}
+    items.update({k: r[k] for k in ("parent", "jtype", "T_origin", "axis", "dof", "mult", "offs", "link_obj", "q_robot", "base_T", "joint_inds", "rot_axis")})
+    items.update(static_T=static_T, traj=traj, d=[d], dist_pen=[dist_pen], coeff=[coeff], n_dof=[rb.n_dof], affine=[rb.affine],
+                 n_joint_inds=[len(rb.joint_inds)])
+    with open(path, "w") as f:
+        for k, v in items.items():
+            v = np.asarray(v).ravel()
+            f.write("%s %d\n%s\n" % (k, len(v), " ".join(repr(float(x)) for x in v)))
+
+
+def read_host_unit_dump(path):
+    """-> meta dict, list of costs {kind, t, value, contacts: [dict]}, list of sweep hits."""
+    meta, costs, sweep = None, [], []
+    for line in open(path):
+        w = line.split()
+        if w[0] == "meta":
+            meta = dict(T=int(w[1]), K=int(w[2]), calls_per_timestep=int(w[3]), calls_prefetched=int(w[4]), prefetch_hits=int(w[5]))
+        elif w[0] == "cost":
+            costs.append(dict(kind=w[1], t=int(w[2]), value=float(w[3]), n=int(w[4]), contacts=[]))
+        elif w[0] == "contact":
+            v = [float(x) for x in w[7:20]]
+            nco = int(w[21])
+            pairs = w[22:22 + 2 * nco]
+            costs[-1]["contacts"].append(dict(
+                idA=int(w[1][1:]), childA=int(w[2]), idB=int(w[3][1:]), childB=int(w[4]), cctype=int(w[5]), time=np.float32(w[6]),
+                dist=v[0], n=v[1:4], ptA=v[4:7], ptB=v[7:10], ptB1=v[10:13], const=float(w[20]),
+                vars=[int(x) for x in pairs[0::2]], coeffs=[float(x) for x in pairs[1::2]]))
+        elif w[0] == "sweep":
+            sweep.append(dict(idA=int(w[1][1:]), childA=int(w[2]), idB=int(w[3][1:]), childB=int(w[4]), toi=np.float32(w[5]), n=[float(x) for x in w[6:9]]))
+    return meta, costs, sweep

@@ -91,9 +91,8 @@ class HIPCollisionChecker:
 
     def ExcludeCollisionPair(self, link0, link1):
         self._excluded.add((link0, link1))
-        self.allowed[link0, link1] = 0
-        self.allowed[link1, link0] = 0       # UpdateAllowedCollisionMatrix clears both directions (:616-627)
-        self.eng.set_allowed_matrix(self.allowed)
+        self.allowed[link0, link1] = 0       # one direction (bullet_collision_checker.cpp:342-346); UpdateAllowedCollisionMatrix
+        self.eng.set_allowed_matrix(self.allowed)   # (:616-627, on the next body change) clears both
 
     def IncludeCollisionPair(self, link0, link1):
         self._excluded.discard((link0, link1))
@@ -114,7 +113,14 @@ class HIPCollisionChecker:
             return
         zero.finalize()
         self.eng.upload_robot(zero)
-        rec, _ = self.eng.links_vs_all_batch(np.zeros((1, zero.K)), 1, 1, filter_mask=-1, want_jacobians=False)
+        # BodyVsAll: EVERY link of the body is a query, not only those a joint moves (collision_checker.cpp:49)
+        T = self.static_T.copy()
+        fk = self.eng.forward_kinematics(np.zeros((1, zero.K)))[0]
+        body = [o for o in rb.link_obj if o >= 0]
+        for i, o in enumerate(rb.link_obj):
+            if o >= 0:
+                T[o] = fk[i]
+        rec = self.eng.links_vs_all_poses(T, body, -1)
         for a, b in zip(rec["idA"].tolist(), rec["idB"].tolist()):
             self.allowed[a, b] = self.allowed[b, a] = 0
             self._excluded.add((a, b))
@@ -225,8 +231,9 @@ def aff_exprs(rec, grads, cast):
     if not cast:
         return rec["const0"].copy(), grads[:, 0].copy(), None
     t = rec["time"].astype(float)
-    const = (1 - t) * rec["const0"] + t * rec["const1"]
-    return const, (1 - t)[:, None] * grads[:, 0], t[:, None] * grads[:, 1]
+    one_minus_t = (np.float32(1) - rec["time"]).astype(float)    # `1-collisions[i].time` is float arithmetic (:73)
+    const = one_minus_t * rec["const0"] + t * rec["const1"]
+    return const, one_minus_t[:, None] * grads[:, 0], t[:, None] * grads[:, 1]
 
 
 class CollisionCost:
