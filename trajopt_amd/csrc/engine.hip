@@ -76,6 +76,7 @@ struct tohc_engine {
   DBuf<F4> d_v4;
   DBuf<unsigned char> d_allowed;
   DBuf<ChildDesc> d_child_desc;
+  DBuf<CullSph> d_stat_sph;
   float d = 0.05f, breaking = 0;
 
   // robot
@@ -249,7 +250,7 @@ void tohc_destroy(tohc_engine *e) {
   DBuf<float> *fb[] = {&e->d_shape_dims, &e->d_shape_lmin, &e->d_shape_lmax, &e->d_vx, &e->d_vy, &e->d_vz, &e->d_child_localT, &e->d_stat_xf,
                        &e->d_stat_aabb, &e->d_dynXf, &e->d_dynAabb, &e->d_dynXf1, &e->d_dynAabb1};
   for (auto b : fb) b->release();
-  e->d_v4.release(); e->d_cl_soaR.release(); e->d_stat_soaR.release(); e->d_stat_soaP.release();
+  e->d_v4.release(); e->d_stat_sph.release(); e->d_cl_soaR.release(); e->d_stat_soaR.release(); e->d_stat_soaP.release();
   DBuf<double> *db[] = {&e->d_T_origin, &e->d_axis, &e->d_mult, &e->d_offs, &e->d_q_robot, &e->d_dofs, &e->d_linkQT, &e->d_objQT, &e->d_objQT1, &e->d_grads};
   for (auto b : db) b->release();
   e->d_allowed.release(); e->d_dbg.release(); e->d_cnt.release(); e->d_records.release();
@@ -294,6 +295,16 @@ static int refreshStatic(tohc_engine *e) {
       for (int k = 0; k < 4; ++k) d.sph[k] = e->h_shape_sph[4 * sh + k];
     }
     HIPCHK(upload(e->d_child_desc, cd, e->stream));
+    // the sphere stage of the pre-test for children that never move: world sphere + filter words in one 32-byte record
+    std::vector<CullSph> cs(e->n_children);
+    for (int c = 0; c < e->n_children; ++c) {
+      CullSph &o = cs[c];
+      memset(&o, 0, sizeof o);
+      const V3 w = xfApply(ldXf(&xf[12 * c]), mk(cd[c].sph[0], cd[c].sph[1], cd[c].sph[2]));
+      o.c[0] = w.x; o.c[1] = w.y; o.c[2] = w.z; o.r = cd[c].sph[3];
+      o.obj = cd[c].obj; o.group = cd[c].group;
+    }
+    HIPCHK(upload(e->d_stat_sph, cs, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
   }
   // SoA cull-box table of the children that never move in robot mode (everything until a robot is uploaded), in
@@ -615,7 +626,7 @@ static DevScene devScene(tohc_engine *e) {
   s.vx = e->d_vx.p; s.vy = e->d_vy.p; s.vz = e->d_vz.p; s.v4 = e->d_v4.p;
   s.child_shape = e->d_child_shape.p; s.child_obj = e->d_child_obj.p; s.child_idx = e->d_child_idx.p; s.child_localT = e->d_child_localT.p;
   s.obj_off = e->d_obj_off.p; s.obj_cnt = e->d_obj_cnt.p; s.obj_compound = e->d_obj_compound.p; s.obj_group = e->d_obj_group.p;
-  s.allowed = e->d_allowed.p; s.stat_xf = e->d_stat_xf.p; s.stat_aabb = e->d_stat_aabb.p; s.child_desc = e->d_child_desc.p;
+  s.allowed = e->d_allowed.p; s.stat_xf = e->d_stat_xf.p; s.stat_aabb = e->d_stat_aabb.p; s.child_desc = e->d_child_desc.p; s.stat_sph = e->d_stat_sph.p;
   return s;
 }
 static DevRobot devRobot(tohc_engine *e) {

@@ -32,6 +32,11 @@ struct ChildDesc {   // 64 B = one cache line per child: cuts the dependent-load
   float pad2;
   float sph[4];      // bounding sphere in the child's frame: centre of its local box, radius (slightly inflated)
 };
+struct CullSph {     // 32 B per child: all the sphere stage of the pre-test needs of a child that never moves
+  float c[3], r;     // its bounding sphere in WORLD coordinates (static pose), radius as ChildDesc::sph[3]
+  int obj, group;
+  int pad[2];
+};
 struct DevScene {
   int n_shapes, n_children, n_objects;
   const int *shape_kind, *shape_voff, *shape_vcnt;
@@ -45,6 +50,7 @@ struct DevScene {
   const struct ChildDesc *child_desc;                 // [n_children] everything the narrowphase needs about a child, packed
   const float *stat_xf;                               // [n_children][12] world transform when the object is static
   const float *stat_aabb;                             // [n_children][6]
+  const struct CullSph *stat_sph;                     // [n_children] world bounding sphere + filter words, as if static
 };
 struct DynMap {          // which objects / children move per set (robot links, or everything in "poses" mode)
   const int *obj_dyn;    // [n_objects]  -> slot or -1
@@ -325,6 +331,7 @@ __device__ __forceinline__ void loadSide(const NarrowArgs &a, int child, const C
 // -----------------------------------------------------------------------------------------------------------------
 #define TOHC_BP_THREADS 64
 #define TOHC_BP_QCAP 256
+#define TOHC_BP_DYN 0x40000000   // queue entries: child number, + this bit when the child moves (came from the scan of the moving children)
 struct CullArgs {
   NarrowArgs a;
   const int *qchildren;
@@ -364,7 +371,7 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
   // The queued box-test survivors, one lane per pair: object-level filters (here and not in the scan loop: they are
   // three dependent loads, which per overlapping cluster made the scan a chain of ~100 L2 round trips per wavefront),
   // pre-test, and what is left goes to the pair list.
-  auto drain = [&]() {
+  auto drain = [&]() __attribute__((always_inline)) {
     __syncthreads();   // one wavefront per block: orders the queue writes before the reads below
     if (ca.pretest && !haveQ) {
       loadSide<1>(a, q, sc.child_desc[q], set0, set1, CAST, cq, tq);
@@ -374,11 +381,24 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
       const unsigned int k = k0 + lane;
       bool keep = k < nq;
       int x = 0;
-      ChildDesc dx;
+      V3 c = mk(0.f, 0.f, 0.f);   // the other child's bounding sphere, world coordinates
+      float rad = 0.f;
       if (keep) {
-        x = s_q[k];
-        dx = sc.child_desc[x];
-        const int X = dx.obj, gx = dx.group;
+        const int ent = s_q[k];
+        x = ent & ~TOHC_BP_DYN;
+        int X, gx;
+        if (ent & TOHC_BP_DYN) {   // a moving child: sphere through its pose of this set
+          const ChildDesc *dd = sc.child_desc + x;
+          X = dd->obj; gx = dd->group;
+          const F4 sl = *reinterpret_cast<const F4 *>(dd->sph);
+          c = xfApply(childXf(a, a.dynXf0, set0, x), mk(sl.x, sl.y, sl.z));
+          rad = sl.w;
+        } else {                   // never moves: one 32-byte record, no pose, no descriptor
+          const CullSph sx = sc.stat_sph[x];
+          X = sx.obj; gx = sx.group;
+          c = mk(sx.c[0], sx.c[1], sx.c[2]);
+          rad = sx.r;
+        }
         keep = (X != Q) && (CAST ? (gx & TOHC_GROUP_KINBODY) != 0 : (gx & (short)cp.filter_mask) != 0)  // cast: KinBodyFilter (bcc:983)
                && allowedRow[X] != 0;
       }
@@ -386,20 +406,20 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
       if (ca.dbg == 1) keep = false;
       if (keep && ca.pretest) {
         // one direction for both stages: from the other child's bounding-sphere centre to the query's origin.
-        // Stage 1 needs nothing of the other child but its descriptor (one cache line) and pose: the query's support
-        // point against the SPHERE bounds the distance from below; ~94 % of what the exact test rejects ends here.
+        // Stage 1 needs nothing of the other child but that sphere: the query's support point against the SPHERE bounds
+        // the distance from below; ~94 % of what the exact test rejects ends here.
         // Stage 2 (the exact support of the other child, a scan of its vertices) only runs for the rest.
-        const Xf tx = childXf(a, a.dynXf0, set0, x);
-        const V3 c = xfApply(tx, mk(dx.sph[0], dx.sph[1], dx.sph[2]));
         const V3 dir = tq.o - c;
         const float dl2 = len2(dir);
         if (dl2 > 1.0e-12f) {
           const float dl = sqrtf(dl2);
           const V3 pA = xfApply(tq, supNV<1>(cq, mulVM(-dir, tq.b)));
-          const float deltaS = dot(dir, pA - c) - dx.sph[3] * dl;
+          const float deltaS = dot(dir, pA - c) - rad * dl;
           if ((deltaS > 0.0f && deltaS > lim * dl) || ca.dbg == 2) {
             keep = false;
           } else {
+            const ChildDesc dx = sc.child_desc[x];
+            const Xf tx = childXf(a, a.dynXf0, set0, x);
             Cvx<1> cx;
             cvxLoad<1>(cx, dx.kind, mk(dx.dims[0], dx.dims[1], dx.dims[2]), sc.vx, sc.vy, sc.vz, sc.v4, dx.voff, dx.vcnt);
             const V3 qB = xfApply(tx, supNV<1>(cx, mulVM(dir, tx.b)));
@@ -429,7 +449,7 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
     __syncthreads();
     nq = 0;
   };
-  auto push = [&](bool hit, int x) {
+  auto push = [&](bool hit, int x) __attribute__((always_inline)) {
     const unsigned long long m = __ballot(hit);
     if (hit) s_q[nq + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = x;
     nq += (unsigned int)__popcll(m);
@@ -492,7 +512,7 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
       chx = dm.dyn_children[i];
       hit = aabbOverlap(bq, ldAabb(ca.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + i) * 6));
     }
-    push(hit, chx);
+    push(hit, chx | TOHC_BP_DYN);
   }
   if (nq > 0) drain();
   if (lane == 0 && ncand > 0) atomicAdd(&a.cnt->sh[shard].n_cand, ncand);
