@@ -737,6 +737,9 @@ static int64_t countAabbTests(const tohc_engine *e, const std::vector<int> &qchi
 }
 
 // broadphase -> GJK -> EPA for one enqueue; `ev` = this enqueue's events [2..5] are recorded here
+#ifndef TOHC_FINISH_BLOCKS_PER_CU
+#define TOHC_FINISH_BLOCKS_PER_CU 4   // with TOHC_FINISH_WAVES 4 (128 VGPRs): four waves per SIMD = 4 blocks of 256 per CU (measured: 2 -> 3 blocks +5 %, 4 / 4 another +3 %)
+#endif
 static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren, const std::vector<int> &h_qchildren, CallParams cp,
                         bool robotMode, int slot, bool append) {
   const int nQ = (int)h_qchildren.size();
@@ -809,7 +812,7 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
     // k_finish appends to the shared slab at the count the previous enqueue's k_bump left
     if (append && prev && prev != &ln) HIPCHK(hipStreamWaitEvent(s, prev->done, 0));
     if (e->group == 64) hipLaunchKernelGGL((k_finish<64>), dim3(256 * 2), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_finish<16>), dim3(256 * 2), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_finish<16>), dim3(256 * TOHC_FINISH_BLOCKS_PER_CU), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, s, e->d_cnt.p + slot, cp.seg_cap, e->d_nrec.p);
     HIPCHK(hipEventRecord(ev[6], s));
     HIPCHK(hipGetLastError());

@@ -1057,7 +1057,10 @@ __device__ __forceinline__ double linearizeFast(const NarrowArgs &a, int set, in
 // k_finish: btBridgedManifoldResult::addContactPoint (btCollisionWorld.cpp:1068-1086), CastCollisionCollector
 // (bullet_collision_checker.cpp:894-972), record + gradient rows.
 template <int G>
-__global__ void __launch_bounds__(256) k_finish(NarrowArgs a) {
+#ifndef TOHC_FINISH_WAVES
+#define TOHC_FINISH_WAVES 4
+#endif
+__global__ void __launch_bounds__(256, TOHC_FINISH_WAVES) k_finish(NarrowArgs a) {
   __shared__ double s_rows[256 / G][2 * TOHC_FAST_JAC_MAXK];
   double *row = s_rows[threadIdx.x / G];
   const bool fast = a.rb.fast_jac != 0;
