@@ -133,9 +133,15 @@ def main():
     s, rb, static_T, d, cc, dofs = build_world(rank, world, P, T)
     eng = cc.eng
 
+    cast_first = os.environ.get("BENCH_CAST_FIRST", "0") == "1"   # timing experiment: which pass is enqueued first
+
     def step():
-        eng.enqueue_links_vs_all(-1, True, append=False)
-        eng.enqueue_cast_vs_all(1, True, append=True)
+        if cast_first:
+            eng.enqueue_cast_vs_all(1, True, append=False)
+            eng.enqueue_links_vs_all(-1, True, append=True)
+        else:
+            eng.enqueue_links_vs_all(-1, True, append=False)
+            eng.enqueue_cast_vs_all(1, True, append=True)
         eng.sync()
 
     def barrier():

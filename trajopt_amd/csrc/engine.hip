@@ -1,7 +1,7 @@
 // engine.hip -- libtrajopt_hipcc.so: the C-ABI of include/trajopt_hipcc.h and the gfx950 kernels behind it.
 //
 // Pipeline of one batch call (all on the engine's own stream, nothing allocates after warm-up):
-//   k_fk -> k_broadphase -> k_gjk -> k_epa -> k_finish -> k_bump      (kernels and layouts: tohc_kernels.h)
+//   k_fk -> k_broadphase -> k_gjk -> k_pen -> k_epa -> k_range -> k_finish     (kernels and layouts: tohc_kernels.h)
 // Static obstacles are transformed once at upload (the reference re-syncs every object on every call,
 // bullet_collision_checker.cpp:629-655).  See DESIGN.md for layouts and rooflines.
 #include <hip/hip_runtime.h>
@@ -106,7 +106,8 @@ struct tohc_engine {
   // appends to the shared record slab, waits for the previous enqueue's.
   struct Lane {
     hipStream_t stream = nullptr;
-    hipEvent_t done = nullptr;       // recorded after the lane's latest k_bump
+    hipEvent_t done = nullptr;       // recorded after the lane's latest k_finish
+    hipEvent_t ranged = nullptr;     // recorded after the lane's latest k_range: the next enqueue may reserve its record range
     DBuf<PairRec> pairs;
     DBuf<EpaRec> epaq;
     DBuf<PenRec> penq;
@@ -119,6 +120,7 @@ struct tohc_engine {
   bool fk_done = false;
   DBuf<unsigned long long> d_dbg;   // TOHC_EPA_PROF builds only
   DBuf<Counters> d_cnt;            // [RING]
+  DBuf<unsigned int> d_rec_base;   // [RING] first record of each enqueue (k_range)
   DBuf<tohc_record> d_records, d_sorted;
   DBuf<double> d_gsorted;
   DBuf<uint64_t> d_sort_keys;
@@ -213,7 +215,8 @@ int tohc_create(tohc_engine **out, int device) {
   if (const char *nc = getenv("TOHC_CHUNKS")) e->chunks = std::min(std::max(atoi(nc), 1), 4);
   if (hipEventCreateWithFlags(&e->ev_fk, hipEventDisableTiming) != hipSuccess) { delete e; return TOHC_E_HIP; }
   for (auto &ln : e->lane)
-    if (hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ln.done, hipEventDisableTiming) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ln.done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ln.ranged, hipEventDisableTiming) != hipSuccess) {
       delete e;
       return TOHC_E_HIP;
     }
@@ -226,7 +229,7 @@ int tohc_create(tohc_engine **out, int device) {
   e->events.resize((size_t)RING * NEV);
   for (auto &ev : e->events)
     if (hipEventCreate(&ev) != hipSuccess) { delete e; return TOHC_E_HIP; }
-  if (e->d_cnt.reserve(RING) != hipSuccess || e->h_cnt.reserve(RING) != hipSuccess || e->d_nrec.reserve(1) != hipSuccess ||
+  if (e->d_cnt.reserve(RING) != hipSuccess || e->d_rec_base.reserve(RING) != hipSuccess || e->h_cnt.reserve(RING) != hipSuccess || e->d_nrec.reserve(1) != hipSuccess ||
       e->h_nrec.reserve(1) != hipSuccess || hipMemset(e->d_nrec.p, 0, sizeof(unsigned int)) != hipSuccess) { delete e; return TOHC_E_HIP; }
   *out = e;
   return TOHC_OK;
@@ -238,6 +241,7 @@ void tohc_destroy(tohc_engine *e) {
   for (auto &ln : e->lane) {
     if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
     if (ln.done) (void)hipEventDestroy(ln.done);
+    if (ln.ranged) (void)hipEventDestroy(ln.ranged);
     ln.pairs.release(); ln.epaq.release(); ln.penq.release(); ln.hits.release();
   }
   if (e->ev_fk) (void)hipEventDestroy(e->ev_fk);
@@ -253,7 +257,7 @@ void tohc_destroy(tohc_engine *e) {
   e->d_v4.release(); e->d_stat_sph.release(); e->d_cl_soaR.release(); e->d_stat_soaR.release(); e->d_stat_soaP.release();
   DBuf<double> *db[] = {&e->d_T_origin, &e->d_axis, &e->d_mult, &e->d_offs, &e->d_q_robot, &e->d_dofs, &e->d_linkQT, &e->d_objQT, &e->d_objQT1, &e->d_grads};
   for (auto b : db) b->release();
-  e->d_allowed.release(); e->d_dbg.release(); e->d_cnt.release(); e->d_records.release();
+  e->d_allowed.release(); e->d_dbg.release(); e->d_cnt.release(); e->d_rec_base.release(); e->d_records.release();
   e->d_sorted.release(); e->d_gsorted.release(); e->d_sort_keys.release(); e->d_sort_idx.release(); e->d_sort_tmp.release();
   e->h_records.release(); e->h_sorted.release(); e->h_grads.release(); e->h_gsorted.release(); e->h_cnt.release();
   (void)hipEventDestroy(e->ev0); (void)hipEventDestroy(e->ev1);
@@ -737,6 +741,9 @@ static int64_t countAabbTests(const tohc_engine *e, const std::vector<int> &qchi
 }
 
 // broadphase -> GJK -> EPA for one enqueue; `ev` = this enqueue's events [2..5] are recorded here
+#ifndef TOHC_EPA_GRID
+#define TOHC_EPA_GRID 2048
+#endif
 #ifndef TOHC_FINISH_BLOCKS_PER_CU
 #define TOHC_FINISH_BLOCKS_PER_CU 4   // with TOHC_FINISH_WAVES 4 (128 VGPRs): four waves per SIMD = 4 blocks of 256 per CU (measured: 2 -> 3 blocks +5 %, 4 / 4 another +3 %)
 #endif
@@ -776,7 +783,7 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
     a.dynXf0 = e->d_dynXf.p; a.dynXf1 = sep1 ? e->d_dynXf1.p : e->d_dynXf.p;
     a.linkQT = robotMode ? e->d_linkQT.p : nullptr;
     a.dofs = robotMode ? e->d_dofs.p : nullptr;
-    a.pairs = ln.pairs.p; a.epaq = ln.epaq.p; a.penq = ln.penq.p; a.hits = ln.hits.p; a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p;
+    a.pairs = ln.pairs.p; a.epaq = ln.epaq.p; a.penq = ln.penq.p; a.hits = ln.hits.p; a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p; a.rec_base = e->d_rec_base.p + slot;
     a.records = e->d_records.p; a.grads = e->d_grads.p; a.dbg = e->d_dbg.p;
     CullArgs ca;
     ca.a = a; ca.qchildren = d_qchildren; ca.nQ = nQ;
@@ -807,17 +814,21 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
     }
     if (e->group == 64) hipLaunchKernelGGL((k_epa<64, 64>), dim3(gridN), dim3(64), 0, s, a);
     else if (e->epa_block == 16) hipLaunchKernelGGL((k_epa<16, 16>), dim3(gridN * 4), dim3(16), 0, s, a);  // one group per wavefront
-    else hipLaunchKernelGGL((k_epa<16, 64>), dim3(gridN), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((k_epa<16, 64>), dim3(TOHC_EPA_GRID), dim3(64), 0, s, a);
     HIPCHK(hipEventRecord(ev[5], s));
-    // k_finish appends to the shared slab at the count the previous enqueue's k_bump left
-    if (append && prev && prev != &ln) HIPCHK(hipStreamWaitEvent(s, prev->done, 0));
+    // k_finish appends to the shared slab: its range starts where the previous enqueue's ends, known as soon as that
+    // one's k_epa is through (k_range) -- the two k_finish kernels themselves run side by side
+    if (append && prev && prev != &ln) HIPCHK(hipStreamWaitEvent(s, prev->ranged, 0));
+    hipLaunchKernelGGL(k_range, dim3(1), dim3(1), 0, s, e->d_cnt.p + slot, cp.seg_cap, e->d_nrec.p, e->d_rec_base.p + slot);
+    HIPCHK(hipEventRecord(ln.ranged, s));
     if (e->group == 64) hipLaunchKernelGGL((k_finish<64>), dim3(256 * 2), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_finish<16>), dim3(256 * TOHC_FINISH_BLOCKS_PER_CU), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, s, e->d_cnt.p + slot, cp.seg_cap, e->d_nrec.p);
     HIPCHK(hipEventRecord(ev[6], s));
     HIPCHK(hipGetLastError());
   } else {
     for (int i = 3; i < NEV; ++i) HIPCHK(hipEventRecord(ev[i], s));
+    if (append && prev && prev != &ln) HIPCHK(hipStreamWaitEvent(s, prev->ranged, 0));   // keeps the chain of ranges in enqueue order
+    HIPCHK(hipEventRecord(ln.ranged, s));
   }
   HIPCHK(hipEventRecord(ln.done, s));
   tohc_engine::Pending pd;
@@ -866,7 +877,7 @@ static int launchSweep(tohc_engine *e, const DynMap &dm, const int *d_qchildren,
     memset(&a, 0, sizeof a);
     a.sc = devScene(e); a.dm = dm; a.rb = devRobot(e); a.cp = cp;
     a.dynXf0 = e->d_dynXf.p; a.dynXf1 = e->d_dynXf.p;
-    a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p; a.records = e->d_records.p;
+    a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p; a.rec_base = e->d_rec_base.p + slot; a.records = e->d_records.p;
     sa.qchildren = d_qchildren; sa.nQ = nQ; sa.dynAabb0 = e->d_dynAabb.p;
     sa.grow = 0.0011f + 4.0e-3f * discMax;
     hipLaunchKernelGGL(k_sweep, dim3((unsigned)blocks), dim3(64), 0, s, sa);

@@ -94,7 +94,9 @@ struct CounterShard {
 };
 struct Counters {
   CounterShard sh[TOHC_NSHARD];
-  unsigned int overflow, pad[31];
+  unsigned int overflow;
+  unsigned int epa_next;   // k_epa's work counter: wavefronts take the next BLOCK / G pairs when they are done with theirs
+  unsigned int pad[30];
 };
 #define TOHC_CNT_STRIDE (sizeof(CounterShard) / sizeof(unsigned int))
 
@@ -277,7 +279,8 @@ struct NarrowArgs {
   PenRec *penq;
   HitRec *hits;
   Counters *cnt;
-  unsigned int *n_records;   // records already in the slab (append) -- bumped by k_bump
+  unsigned int *n_records;   // records the slab holds once every enqueue so far has finished -- advanced by k_range
+  const unsigned int *rec_base;   // where this enqueue's records start (k_range wrote it before k_finish runs)
   tohc_record *records;
   double *grads;             // [max_records][2][K]
   unsigned long long *dbg;   // diagnostics (TOHC_EPA_PROF builds), else null
@@ -896,8 +899,6 @@ template <int G, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, TOHC_EPA_WAVES) k_epa(NarrowArgs a) {
   __shared__ EpaMem mem[BLOCK / G];
   const int groupsPerBlock = BLOCK / G;
-  const unsigned int gid = blockIdx.x * groupsPerBlock + threadIdx.x / G;
-  const unsigned int ngroups = gridDim.x * groupsPerBlock;
   const unsigned int cap2 = a.cp.seg_cap / TOHC_PEN_DIV;
   QPrefix pre;
   qprefix(&a.cnt->sh[0].n_pen, cap2, pre);
@@ -905,7 +906,15 @@ __global__ void __launch_bounds__(BLOCK, TOHC_EPA_WAVES) k_epa(NarrowArgs a) {
   EpaMem *m = &mem[threadIdx.x / G];
   float md2 = a.cp.breaking;
   md2 *= md2;
-  for (unsigned int i = gid; i < npen; i += ngroups) {
+  // Pairs are handed out on demand, BLOCK / G at a time per wavefront (a block is one wavefront or less): EPA runs take
+  // from 2 to 255 iterations, and with a fixed share per group the kernel lasted as long as its unluckiest group.
+  for (;;) {
+    unsigned int first = 0;
+    if (threadIdx.x == 0) first = atomicAdd(&a.cnt->epa_next, (unsigned int)groupsPerBlock);
+    first = __shfl(first, 0);
+    if (first >= npen) break;
+    const unsigned int i = first + threadIdx.x / G;
+    if (i >= npen) continue;
     const PenRec *r = &a.penq[qlocate(pre, cap2, i)];
     const EpaRec e = r->e;
     Cvx<G> A, B;
@@ -1070,7 +1079,7 @@ __global__ void __launch_bounds__(256, TOHC_FINISH_WAVES) k_finish(NarrowArgs a)
   QPrefix pre;
   qprefix(&a.cnt->sh[0].n_hits, a.cp.seg_cap, pre);
   const unsigned int nhits = pre.start[TOHC_NSHARD];
-  const unsigned int base = *a.n_records;
+  const unsigned int base = *a.rec_base;
   const int gl = Grp<G>::lane();
   for (unsigned int hIdx = gid; hIdx < nhits; hIdx += ngroups) {
     const unsigned int slot = base + hIdx;
@@ -1143,10 +1152,12 @@ __global__ void __launch_bounds__(256, TOHC_FINISH_WAVES) k_finish(NarrowArgs a)
   }
 }
 
-// after k_finish: the slab now holds base + hits records
-__global__ void k_bump(Counters *cnt, unsigned int segCap, unsigned int *n_records) {
+// between k_epa and k_finish: the hit count of this enqueue is final, so its record range is too.  Enqueues reserve
+// their ranges in enqueue order (an event chain between the lanes); their k_finish kernels then run independently.
+__global__ void k_range(Counters *cnt, unsigned int segCap, unsigned int *n_records, unsigned int *rec_base) {
   QPrefix pre;
   qprefix(&cnt->sh[0].n_hits, segCap, pre);
+  *rec_base = *n_records;
   *n_records += pre.start[TOHC_NSHARD];
 }
 
