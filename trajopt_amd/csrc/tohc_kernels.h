@@ -367,19 +367,25 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
   const unsigned char *allowedRow = sc.allowed + (size_t)Q * sc.n_objects;
   const float lim = cp.d * 1.01f + 1.0e-4f;  // guard band: the bound and Bullet's result both carry ~1e-6 of rounding
   unsigned int nq = 0, ncand = 0;            // wave-uniform
-  bool haveQ = false;
+  // the query side of the pre-test (descriptor -> pose(s)): issued here so that these dependent loads travel together
+  // with the scan's instead of starting a chain of their own at the first drain
   Cvx<1> cq;
   Xf tq;
+  if (ca.pretest) loadSide<1>(a, q, sc.child_desc[q], set0, set1, CAST, cq, tq);
+  // first block of the moving children's boxes, likewise ahead of the scan of the static table
+  int dyn0 = 0;
+  Aabb bd0;
+  bd0.lo = mk(1.f, 1.f, 1.f); bd0.hi = mk(-1.f, -1.f, -1.f);
+  if (lane < dm.n_dyn_children && ca.dbg != 4) {
+    dyn0 = dm.dyn_children[lane];
+    bd0 = ldAabb(ca.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + lane) * 6);
+  }
 
   // The queued box-test survivors, one lane per pair: object-level filters (here and not in the scan loop: they are
   // three dependent loads, which per overlapping cluster made the scan a chain of ~100 L2 round trips per wavefront),
   // pre-test, and what is left goes to the pair list.
   auto drain = [&]() __attribute__((always_inline)) {
     __syncthreads();   // one wavefront per block: orders the queue writes before the reads below
-    if (ca.pretest && !haveQ) {
-      loadSide<1>(a, q, sc.child_desc[q], set0, set1, CAST, cq, tq);
-      haveQ = true;
-    }
     for (unsigned int k0 = 0; k0 < nq; k0 += TOHC_BP_THREADS) {
       const unsigned int k = k0 + lane;
       bool keep = k < nq;
@@ -506,8 +512,9 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
       }
     }
   }
-  // moving children
-  for (int base = 0; base < (ca.dbg == 4 ? 0 : dm.n_dyn_children); base += TOHC_BP_THREADS) {
+  // moving children (the first block was loaded at the top)
+  if (ca.dbg != 4 && dm.n_dyn_children > 0) push(lane < dm.n_dyn_children && aabbOverlap(bq, bd0), dyn0 | TOHC_BP_DYN);
+  for (int base = TOHC_BP_THREADS; base < (ca.dbg == 4 ? 0 : dm.n_dyn_children); base += TOHC_BP_THREADS) {
     const int i = base + lane;
     bool hit = false;
     int chx = 0;
