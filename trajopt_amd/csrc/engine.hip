@@ -90,6 +90,7 @@ struct tohc_engine {
   // dynamic maps: robot mode and all-objects ("poses") mode
   std::vector<int> h_obj_dynR, h_child_dynR, h_dyn_childrenR, h_qchildrenR;
   std::vector<int> h_obj_dynP, h_child_dynP, h_dyn_childrenP;
+  std::vector<int> h_qinfoR, h_qinfoP;   // what d_qchildrenR / d_qchildrenP hold: 4 ints per query child (queryInfo)
   DBuf<int> d_obj_dynR, d_child_dynR, d_dyn_childrenR, d_qchildrenR, d_obj_dynP, d_child_dynP, d_dyn_childrenP, d_qchildrenP;
   int n_dyn_objR = 0, n_dyn_childrenR = 0;
   // children that never move in each mode, with their cull boxes as an SoA table [6][n_stat_pad]
@@ -187,6 +188,15 @@ static hipError_t upload(DBuf<T> &b, const T *src, size_t n, hipStream_t s) {
 template <class T>
 static hipError_t upload(DBuf<T> &b, const std::vector<T> &v, hipStream_t s) { return upload(b, v.data(), v.size(), s); }
 
+// query children travel to the device as (child, its object, its slot among the moving children or -1, 0): one 16-byte
+// load at the head of k_broadphase / k_sweep instead of a chain of three
+static std::vector<int> queryInfo(const tohc_engine *e, const std::vector<int> &q, const std::vector<int> &child_dyn) {
+  std::vector<int> out(4 * q.size());
+  for (size_t i = 0; i < q.size(); ++i) {
+    out[4 * i] = q[i]; out[4 * i + 1] = e->h_child_obj[q[i]]; out[4 * i + 2] = child_dyn[q[i]]; out[4 * i + 3] = 0;
+  }
+  return out;
+}
 static float safeMargin(float cur, float x, float y, float z) {  // btConvexInternalShape::setSafeMargin, btConvexInternalShape.h:70-85
   float mn = x < y ? (x < z ? x : z) : (y < z ? y : z);
   float safe = 0.1f * mn;
@@ -574,7 +584,8 @@ int tohc_upload_robot(tohc_engine *e, int n_links, const int32_t *parent, const 
     HIPCHK(hipStreamSynchronize(s));
   }
   HIPCHK(upload(e->d_obj_dynR, e->h_obj_dynR, s)); HIPCHK(upload(e->d_child_dynR, e->h_child_dynR, s));
-  HIPCHK(upload(e->d_dyn_childrenR, e->h_dyn_childrenR, s)); HIPCHK(upload(e->d_qchildrenR, e->h_qchildrenR, s));
+  HIPCHK(upload(e->d_dyn_childrenR, e->h_dyn_childrenR, s)); e->h_qinfoR = queryInfo(e, e->h_qchildrenR, e->h_child_dynR);
+  HIPCHK(upload(e->d_qchildrenR, e->h_qinfoR, s));
   HIPCHK(hipStreamSynchronize(s));
   e->have_robot = true;
   return refreshStatic(e);
@@ -1100,7 +1111,8 @@ static int posesQuery(tohc_engine *e, const double *obj_T, const double *cast_T1
   HIPCHK(hipEventRecord(ev[1], s));
   const size_t nobj = e->n_objects, nch = e->n_children;
   HIPCHK(upload(e->d_objQT, obj_T, (size_t)n_sets * nobj * 7, s));
-  HIPCHK(upload(e->d_qchildrenP, qch, s));
+  e->h_qinfoP = queryInfo(e, qch, e->h_child_dynP);
+  HIPCHK(upload(e->d_qchildrenP, e->h_qinfoP, s));
   HIPCHK(e->d_dynXf.reserve((size_t)n_sets * nch * 12)); HIPCHK(e->d_dynAabb.reserve((size_t)n_sets * nch * 6));
   DynMap dm = dynMapPoses(e);
   const size_t tot = (size_t)n_sets * nch;
@@ -1200,7 +1212,8 @@ int tohc_continuous_check_poses(tohc_engine *e, const double *obj_T, int n_steps
   HIPCHK(hipEventRecord(ev[1], s));
   const size_t nobj = e->n_objects, nch = e->n_children;
   HIPCHK(upload(e->d_objQT, obj_T, (size_t)n_steps * nobj * 7, s));
-  HIPCHK(upload(e->d_qchildrenP, qch, s));
+  e->h_qinfoP = queryInfo(e, qch, e->h_child_dynP);
+  HIPCHK(upload(e->d_qchildrenP, e->h_qinfoP, s));
   HIPCHK(e->d_dynXf.reserve((size_t)n_steps * nch * 12)); HIPCHK(e->d_dynAabb.reserve((size_t)n_steps * nch * 6));
   DynMap dm = dynMapPoses(e);
   const size_t tot = (size_t)n_steps * nch;

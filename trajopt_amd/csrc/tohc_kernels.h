@@ -356,12 +356,13 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
   const int lane = threadIdx.x;
   const int qi = blockIdx.x % ca.nQ;
   const int cs = cp.unit_base + blockIdx.x / ca.nQ;
-  const int q = ca.qchildren[qi];
-  const int Q = sc.child_obj[q];
+  const int4 qinfo = reinterpret_cast<const int4 *>(ca.qchildren)[qi];   // (child, object, moving slot or -1, 0)
+  const int q = qinfo.x;
+  const int Q = qinfo.y;
   const int shard = blockIdx.x % TOHC_NSHARD;
   int set0, set1;
   castSets(cp, cs, set0, set1);
-  const int qs = dm.child_dyn[q];
+  const int qs = qinfo.z;
   Aabb bq = qs >= 0 ? ldAabb(ca.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + qs) * 6) : ldAabb(sc.stat_aabb + 6 * q);
   if (CAST && qs >= 0) bq = aabbUnion(bq, ldAabb(ca.dynAabb1 + ((size_t)set1 * dm.n_dyn_children + qs) * 6));
   const unsigned char *allowedRow = sc.allowed + (size_t)Q * sc.n_objects;
@@ -561,7 +562,7 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs sa) {
   const int lane = threadIdx.x, grp = lane >> 4;
   const int qi = blockIdx.x % sa.nQ;
   const int cs = cp.unit_base + blockIdx.x / sa.nQ;
-  const int q = sa.qchildren[qi];
+  const int q = sa.qchildren[4 * qi];
   int set0, set1;
   castSets(cp, cs, set0, set1);
   const ChildDesc dq = sc.child_desc[q];
