@@ -391,11 +391,13 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
       const unsigned int k = k0 + lane;
       bool keep = k < nq;
       int x = 0;
+      bool xDyn = false;
       V3 c = mk(0.f, 0.f, 0.f);   // the other child's bounding sphere, world coordinates
       float rad = 0.f;
       if (keep) {
         const int ent = s_q[k];
         x = ent & ~TOHC_BP_DYN;
+        xDyn = (ent & TOHC_BP_DYN) != 0;
         int X, gx;
         if (ent & TOHC_BP_DYN) {   // a moving child: sphere through its pose of this set
           const ChildDesc *dd = sc.child_desc + x;
@@ -429,7 +431,8 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
             keep = false;
           } else {
             const ChildDesc dx = sc.child_desc[x];
-            const Xf tx = childXf(a, a.dynXf0, set0, x);
+            // (a child that never moves: its pose straight from the static table, no look-up of its slot first)
+            const Xf tx = xDyn ? childXf(a, a.dynXf0, set0, x) : ldXf(sc.stat_xf + 12 * x);
             Cvx<1> cx;
             cvxLoad<1>(cx, dx.kind, mk(dx.dims[0], dx.dims[1], dx.dims[2]), sc.vx, sc.vy, sc.vz, sc.v4, dx.voff, dx.vcnt);
             const V3 qB = xfApply(tx, supNV<1>(cx, mulVM(dir, tx.b)));
