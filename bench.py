@@ -24,12 +24,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# HBM bytes per launch from the PMC counters: profiles/r01_f_hbm_traffic_pmc.csv, collected on this workload (64
+# HBM bytes per launch from the PMC counters: profiles/r01_h_hbm_traffic_pmc.csv, collected on this workload (64
 # problems per GPU, scripts/profile_bench.sh) as MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE in separate
 # passes, bytes = (2*FETCH + WRITE) * 1024), mean of the discrete and the cast launch; "epa" = k_pen + k_epa.  Far below
 # the algorithmic bytes for the broadphase and GJK kernels because the 2 MB of hull vertices and the box table are
 # re-read from L2 / Infinity Cache, not HBM.
-TRAFFIC_BYTES_PER_LAUNCH = {"broadphase": 205.6e6, "gjk": 43.5e6, "epa": 46.3e6, "finish": 341.7e6}
+TRAFFIC_BYTES_PER_LAUNCH = {"broadphase": 282.3e6, "gjk": 44.6e6, "epa": 42.7e6, "finish": 385.6e6}
 
 
 def build_world(rank, world, problems, T=100):
