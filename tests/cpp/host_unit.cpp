@@ -319,6 +319,14 @@ static void test_linearize(const string& in, const string& out) {
       EXPECT_TRUE(a.constant == b.constant && a.coeffs == b.coeffs);
     }
   }
+  // IgnoreZeroStateSelfCollisions() once more, now with a configuration bound (collision_checker.cpp:58-66): the robot is
+  // lifted to z = 10 by SetTransform, which the bound DOF vector cannot express -- nothing may change
+  {
+    checker->IgnoreZeroStateSelfCollisions();
+    Pass C = runCosts(W, x, false);
+    EXPECT_EQ(A.values.size(), C.values.size());
+    for (size_t i = 0; i < A.values.size() && i < C.values.size(); ++i) EXPECT_TRUE(A.values[i] == C.values[i]);
+  }
   // CollisionConstraint is the same arithmetic scaled by coeff (collision_terms.cpp:244-262)
   {
     VarVector v(K);

@@ -411,7 +411,12 @@ const HIPCollisionChecker::Prefetched* HIPCollisionChecker::FindPrefetched(const
 void HIPCollisionChecker::LinksVsAll(const vector<KinBody::LinkPtr>& links, vector<Collision>& collisions, short filterMask) {   // :500-510
   UpdateFromRave();
   if (m_obj2link.empty()) return;
-  if (m_bound && IsAffectedSet(links)) {
+  // The linearizing route runs FK on the device from the bound configuration's DOF vector, so it only applies while
+  // that vector describes the robot's state: with affine DOFs, while the body transform is the one last set through a
+  // RobotAndDOF (IgnoreZeroStateSelfCollisions lifts the body to z = 10 by SetTransform: explicit-pose route then).
+  DblVec aff;
+  const bool representable = m_bound && (m_bound->affinedofs == 0 || m_bound->robot->GetCachedAffineDOFValues(m_bound->affinedofs, m_bound->rotationaxis, aff));
+  if (representable && IsAffectedSet(links)) {
     // the query the collision terms make (collision_terms.cpp:118-122): contacts AND their linearization
     DblVec q = m_bound->GetDOFValues();
     if (const Prefetched* p = FindPrefetched(q, NULL, filterMask)) {
