@@ -50,7 +50,7 @@ def rank_device(rank):
     return int(os.environ.get("LOCAL_RANK", rank))
 
 
-def cpu_baseline(s, rb, static_T, d, allowed, trajs, budget_s=12.0):
+def cpu_baseline(s, rb, static_T, d, allowed, trajs, budget_s=12.0, only=None):
     """The CPU path on ONE host core, on a bounded sample of the same workload: timesteps of the rank's problems, each
     problem taken with a stride of 7, problem after problem until ~budget_s of work.  kind=reference: the reference's own vendored Bullet (oracle/_ref) doing
     LinksVsAll + CastVsAll on poses from the oracle's FK (FK / Jacobian time NOT charged to it);
@@ -66,7 +66,7 @@ def cpu_baseline(s, rb, static_T, d, allowed, trajs, budget_s=12.0):
     t0 = time.perf_counter()
     pe0 = wo.counter(0)
     used = 0
-    for p, t in order:
+    for p, t in (order if only != "reference" else []):
         wo.linearize(rb, static_T, trajs[p, t:t + 1])
         wo.linearize(rb, static_T, trajs[p, t:t + 2], cast=True)
         used += 1
@@ -74,6 +74,9 @@ def cpu_baseline(s, rb, static_T, d, allowed, trajs, budget_s=12.0):
             break
     dt = time.perf_counter() - t0
     out["port"] = dict(value=(wo.counter(0) - pe0) / dt, seconds=dt, timesteps=used)
+    if only == "port":
+        wo.close()
+        return out
     if B.ref_available():
         wr = B.ref_world(s, cap=1 << 18)
         wr.set_contact_distance(d)
@@ -107,7 +110,43 @@ def cpu_baseline(s, rb, static_T, d, allowed, trajs, budget_s=12.0):
     return out
 
 
+def cpu_worker(idx, n, problems, budget_s):
+    """One of the n worker processes of the all-cores CPU baseline: the same bounded sample, on the problems idx, idx+n, ..."""
+    from trajopt_amd import multi_gpu, synth
+    from oracle import bindings as B
+    s, rb, static_T, d = synth.config_fullbody_soup()
+    allowed = np.load(os.environ["BENCH_ALLOWED"])
+    mine = list(range(idx, problems, n)) or [idx % problems]
+    trajs = np.stack([synth.fullbody_trajectory(rb, np.random.default_rng(1000 + g), 100) for g in mine])
+    cb = cpu_baseline(s, rb, static_T, d, allowed, trajs, budget_s=budget_s, only="reference" if B.ref_available() else "port")
+    k = "reference" if "reference" in cb else "port"
+    print(json.dumps({"kind": k, "pair_evals": cb[k]["value"] * cb[k]["seconds"], "seconds": cb[k]["seconds"]}), flush=True)
+
+
+def cpu_baseline_all_cores(allowed, problems, budget_s=10.0):
+    """The same CPU path on every host core the job may use (the box gives a one-GPU job 16): independent worker
+    processes (children started with subprocess, each its own interpreter; none touches the GPU), one per core, each
+    over its own problems for ~budget_s; rate = summed pair-evals / longest worker time."""
+    import subprocess
+    import tempfile
+    n = max(1, min(16, len(os.sched_getaffinity(0))))
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "allowed.npy")
+        np.save(path, allowed)
+        env = dict(os.environ, BENCH_ALLOWED=path, OMP_NUM_THREADS="1")
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i), str(n), str(problems), str(budget_s)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for i in range(n)]
+        outs = [p.communicate(timeout=180)[0] for p in procs]
+    res = [json.loads(o.strip().splitlines()[-1]) for o, p in zip(outs, procs) if p.returncode == 0 and o.strip()]
+    if not res:
+        return None
+    return {"value": sum(r["pair_evals"] for r in res) / max(r["seconds"] for r in res), "cores": len(res), "kind": res[0]["kind"]}
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -282,6 +321,10 @@ def main():
                                    "sample": "%d (problem, timestep) units of this rank's workload (%.1f s of CPU work): discrete LinksVsAll + CastVsAll per unit on one core"
                                              % (cb[kind]["timesteps"], cb[kind]["seconds"]),
                                    "port_value": cb["port"]["value"]}
+            try:   # the same on every host core of the job (north-star: "timed on the box's host cores, with the core count stated")
+                out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(cc.allowed, P)
+            except Exception as ex:   # a reported extra: never fails the bench
+                out["cpu_baseline"]["all_cores"] = {"error": str(ex)[:200]}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
