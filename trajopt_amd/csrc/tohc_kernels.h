@@ -334,6 +334,9 @@ __device__ __forceinline__ void loadSide(const NarrowArgs &a, int child, const C
 // -----------------------------------------------------------------------------------------------------------------
 #define TOHC_BP_THREADS 64
 #define TOHC_BP_QCAP 256
+#ifndef TOHC_BP_EXACT
+#define TOHC_BP_EXACT 1   // 0: no exact stage here; what the sphere stage passes goes to k_gjk, whose first iterations end far pairs too
+#endif
 #define TOHC_BP_DYN 0x40000000   // queue entries: child number, + this bit when the child moves (came from the scan of the moving children)
 struct CullArgs {
   NarrowArgs a;
@@ -429,7 +432,7 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
           const float deltaS = dot(dir, pA - c) - rad * dl;
           if ((deltaS > 0.0f && deltaS > lim * dl) || ca.dbg == 2) {
             keep = false;
-          } else {
+          } else if (TOHC_BP_EXACT) {
             const ChildDesc dx = sc.child_desc[x];
             // (a child that never moves: its pose straight from the static table, no look-up of its slot first)
             const Xf tx = xDyn ? childXf(a, a.dynXf0, set0, x) : ldXf(sc.stat_xf + 12 * x);
