@@ -314,7 +314,7 @@ def main():
                                  "iterative fp32 algorithm), far below the HBM roof by nature; bytes are compulsory only (SURVEY 8d)"},
             "roofline_all": roof_all,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 at N = 1 only
             cb = cpu_baseline(s, rb, static_T, d, cc.allowed, dofs)
             kind = "reference" if "reference" in cb else "port"
             out["cpu_baseline"] = {"value": cb[kind]["value"], "unit": "pair-evals/s", "cores": 1, "kind": kind,
