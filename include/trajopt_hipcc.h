@@ -158,6 +158,17 @@ int tohc_continuous_check_trajectory(tohc_engine *e, const double *dofs, int B, 
 int tohc_continuous_check_poses(tohc_engine *e, const double *obj_T, int n_steps, const int32_t *query, int n_query,
                                 const tohc_record **records, int *n_records);
 
+/* replaces BulletCollisionChecker::RayCastCollision                           bullet_collision_checker.cpp:352-360
+ * (btCollisionWorld::rayTest with a ClosestRayResultCallback -> btSubsimplexConvexCast::calcTimeOfImpact per convex
+ * geometry), for a batch of rays against ONE configuration.  from / to: [n_rays][3] world points;
+ * closest_fraction[i] = the callback's m_closestHitFraction in [0, 1]: 1 = nothing hit, so the reference's return value
+ * (hasHit()) is closest_fraction[i] < 1.  Every object takes part (robot links too); like the reference it ignores the
+ * allowed-pair matrix and the contact distance.  dofs: [K], the robot's configuration (the reference reads it from the
+ * OpenRAVE environment at call time, UpdateBulletFromRave :356). */
+int tohc_ray_cast(tohc_engine *e, const double *dofs, const double *from, const double *to, int n_rays, float *closest_fraction);
+/* the same on explicit poses: obj_T [n_objects][7] */
+int tohc_ray_cast_poses(tohc_engine *e, const double *obj_T, const double *from, const double *to, int n_rays, float *closest_fraction);
+
 /* device FK only (diagnostics / tests): link_T [B*T][n_links][7] */
 int tohc_forward_kinematics(tohc_engine *e, const double *dofs, int n_cfg, double *link_T);
 

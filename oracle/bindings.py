@@ -190,6 +190,20 @@ class World:
         assert n <= self.cap
         return out[:n].copy()
 
+    def ray_cast(self, objT, p_from, p_to):
+        """RayCastCollision for a batch of rays -> float32[n] closest hit fractions (1 = no hit; hit <=> < 1)"""
+        fn = self.f("ray_cast")
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_float)]
+        objT = np.ascontiguousarray(objT, np.float64).reshape(-1, 7)
+        assert len(objT) == self.scene.n_objects
+        a = np.ascontiguousarray(p_from, np.float64).reshape(-1, 3)
+        b = np.ascontiguousarray(p_to, np.float64).reshape(-1, 3)
+        assert len(a) == len(b)
+        out = np.ones(len(a), np.float32)
+        fn(self.h, _p(objT, C.c_double), _p(a, C.c_double), _p(b, C.c_double), len(a), _p(out, C.c_float))
+        return out
+
     def sweep_pair(self, Q, qc, T0, T1, X, xc, XT):
         """oracle only: time of impact of ONE (swept geometry, resting geometry) pair -> SWEEP_DTYPE record or None"""
         self.lib.ora_sweep_pair.restype = C.c_int

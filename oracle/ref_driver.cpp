@@ -415,6 +415,24 @@ int ref_continuous_check(void* h, const double* objT, const int* q, int nq, cons
   return n;
 }
 
+/* RayCastCollision (bullet_collision_checker.cpp:352-360) through the reference's own btCollisionWorld::rayTest;
+ * closest[i] = the callback's m_closestHitFraction (1 = no hit). */
+int ref_ray_cast(void* h, const double* objT, const double* from3, const double* to3, int n_rays, float* closest) {
+  World* w = (World*)h;
+  syncWorld(w, objT);
+  w->world->updateAabbs();
+  int hits = 0;
+  for (int i = 0; i < n_rays; ++i) {
+    btVector3 btFrom((float)from3[3 * i], (float)from3[3 * i + 1], (float)from3[3 * i + 2]);
+    btVector3 btTo((float)to3[3 * i], (float)to3[3 * i + 1], (float)to3[3 * i + 2]);
+    btCollisionWorld::ClosestRayResultCallback res(btFrom, btTo);
+    w->world->rayTest(btFrom, btTo, res);
+    closest[i] = res.m_closestHitFraction;
+    hits += res.hasHit() ? 1 : 0;
+  }
+  return hits;
+}
+
 /* Post-construction vertex data of a shape, for hull shapes built elsewhere (diagnostics). */
 int ref_gjk_checks(void) { return gNumGjkChecks; }
 int ref_epa_checks(void) { return gNumDeepPenetrationChecks; }

@@ -1771,6 +1771,89 @@ int ora_continuous_check(void *h, const double *objT7, const int *q, int nq, con
 }
 
 /* ------------------------------------------------------------------------------------------------------ */
+/* RayCastCollision [bcc:352-360]: btCollisionWorld::rayTest [cw:916-932] with a ClosestRayResultCallback     */
+/* ------------------------------------------------------------------------------------------------------ */
+static v3 interp3(v3 a, v3 b, float rt) { /* btVector3::setInterpolate3, scalar branch [btVector3.h:494-497] */
+  float s = 1.0f - rt;
+  return V(s * a.x + rt * b.x, s * a.y + rt * b.y, s * a.z + rt * b.z);
+}
+/* btSubsimplexConvexCast::calcTimeOfImpact [btSubSimplexConvexCast.cpp:38-156] as rayTestSingleInternal calls it
+ * [cw:279-301]: convexA is btSphereShape(0) with margin 0 -- its support vertex is (0,0,0) in every direction --,
+ * fromA / toA are identity rotations at the ray's ends [cw:856-859], B rests (fromB == toB == its world transform) and
+ * answers through the VIRTUAL localGetSupportingVertex (margin 0 for box / hull / cylinder, the radius for a sphere). */
+static int rayConvex(const shape_t *sB, const xf *tB, v3 from, v3 to, float *fraction, v3 *normal) {
+  vss_t sx;
+  vssReset(&sx);
+  v3 linVelA = vsub(to, from), linVelB = vsub(tB->o, tB->o);
+  float lambda = 0.0f;
+  v3 oA = from;
+  xf iB = *tB; /* interpolatedTransB: only its origin is ever rewritten */
+  v3 r = vsub(linVelA, linVelB);
+  const v3 zero = V(0, 0, 0);
+  v3 supA = vadd(zero, oA);
+  v3 supB = xfApply(tB, supPlainVirtual(sB, mulVM(r, &tB->b)));
+  v3 v = vsub(supA, supB);
+  int maxIter = 32; /* MAX_ITERATIONS, single precision */
+  v3 n = V(0, 0, 0);
+  float dist2 = vlen2(v);
+  const float epsilon = 0.0001f;
+  while ((dist2 > epsilon) && maxIter--) {
+    supA = vadd(zero, oA);
+    supB = xfApply(&iB, supPlainVirtual(sB, mulVM(v, &iB.b)));
+    v3 w = vsub(supA, supB);
+    float VdotW = vdot(v, w);
+    if (lambda > 1.0f) return 0;
+    if (VdotW > 0.0f) {
+      float VdotR = vdot(v, r);
+      if (VdotR >= -(SIMD_EPSILON * SIMD_EPSILON)) return 0;
+      lambda = lambda - VdotW / VdotR;
+      oA = interp3(from, to, lambda);
+      iB.o = interp3(tB->o, tB->o, lambda); /* s*o + rt*o: not always o again in fp32 */
+      n = v;
+    }
+    if (!vssInSimplex(&sx, w)) vssAdd(&sx, w, supA, supB);
+    int ok = vssUpdate(&sx); /* closest(v): v = m_cachedV whatever the outcome [vss.cpp:263-268] */
+    v = sx.cV;
+    dist2 = ok ? vlen2(v) : 0.0f;
+  }
+  *fraction = lambda;
+  *normal = (vlen2(n) >= (SIMD_EPSILON * SIMD_EPSILON)) ? vdiv(n, vlen(n)) : V(0, 0, 0);
+  if (vdot(*normal, r) >= -0.0f) return 0; /* -result.m_allowedPenetration */
+  return 1;
+}
+
+/* closest[i] = ClosestRayResultCallback::m_closestHitFraction after rayTest(from_i, to_i): 1 when nothing was hit
+ * (RayCastCollision returns hasHit(), i.e. closest < 1).  Every object takes part: the callback's group / mask are
+ * DefaultFilter / AllFilter and the proxies' masks are AllFilter [cw:RayResultCallback::needsCollision]; the allowed-
+ * pair matrix is not consulted.  No cull: Bullet's DBVT ray cull works on boxes grown by >= 3.001 d (and history
+ * dependent fat margins); a hit needs a point of the segment within sqrt(1e-4) = 1 cm of the shape (or 32 iterations
+ * without convergence), so for d >= 3.4 mm the cull cannot remove a hit. */
+int ora_ray_cast(void *h, const double *objT7, const double *from3, const double *to3, int n_rays, float *closest) {
+  world_t *w = (world_t *)h;
+  int hits = 0;
+  xf *T = (xf *)malloc(sizeof(xf) * (w->n_objects + 1));
+  for (int i = 0; i < w->n_objects; ++i) T[i] = xfFrom7(objT7 + 7 * i);
+  for (int i = 0; i < n_rays; ++i) {
+    v3 from = V((float)from3[3 * i], (float)from3[3 * i + 1], (float)from3[3 * i + 2]); /* toBt [bcc:66-68] */
+    v3 to = V((float)to3[3 * i], (float)to3[3 * i + 1], (float)to3[3 * i + 2]);
+    float cl = 1.0f;
+    for (int X = 0; X < w->n_objects && cl != 0.0f; ++X) /* btSingleRayCallback::process stops at 0 [cw:881-882] */
+      for (int xc = 0; xc < w->obj_cnt[X]; ++xc) {
+        xf tx = childWorld(w, X, xc, &T[X]);
+        float fr;
+        v3 nrm;
+        if (!rayConvex(&w->shapes[w->child_shape[w->obj_off[X] + xc]], &tx, from, to, &fr, &nrm)) continue;
+        if (!(vlen2(nrm) > 0.0001f)) continue; /* [cw:304] */
+        if (fr < cl) cl = fr;                  /* [cw:306], ClosestRayResultCallback::addSingleResult */
+      }
+    closest[i] = cl;
+    hits += cl < 1.0f;
+  }
+  free(T);
+  return hits;
+}
+
+/* ------------------------------------------------------------------------------------------------------ */
 /* FK, point Jacobian and contact -> affine expression (fp64)                                                */
 /*   [cs:12-23,83-133] delegate to OpenRAVE, which is absent: conventions are documented in oracle_api.h.   */
 /*   [ct:37-80] CollisionsToDistanceExpressions.                                                             */

@@ -119,6 +119,18 @@ static void test_continuous_boxes() {
       EXPECT_EQ((float)col.const1, 0.4736842f);   // time of impact, DESIGN.md 2 (bit-exact vs the reference's convexSweepTest)
     }
   }
+  {
+    // RayCastCollision (bullet_collision_checker.cpp:352-360): box at the origin (the boxbot, wherever the sweep left it, is not on these rays' first hit);
+    // fractions are the reference Bullet's own (tests/test_oracle_cpu.py RAY_CASES)
+    EXPECT_TRUE(checker->RayCastCollision(Vector(-2, 0, 0), Vector(2, 0, 0)));
+    EXPECT_TRUE(!checker->RayCastCollision(Vector(-2, 0, 3), Vector(2, 0, 3)));     // passes above both boxes
+    EXPECT_TRUE(!checker->RayCastCollision(Vector(0, 0, 3), Vector(0, 0, 2.6)));    // ends before them
+    EXPECT_TRUE(!checker->RayCastCollision(Vector(0, 0, 0), Vector(0, 0, 3)));      // starts inside: the cast reports nothing
+    HIPCollisionChecker* hip = dynamic_cast<HIPCollisionChecker*>(checker.get());
+    vector<float> fr = hip->RayCastCollisions({-2, 0, 0, -2, 0.3, 0.1}, {2, 0, 0, 2, -0.2, 0.3});
+    EXPECT_EQ(fr[0], 0.375f);
+    EXPECT_EQ(fr[1], 0.37474722f);
+  }
   struct Case { double q0[2], q1[2]; Vector n; double time, ttol; };
   const double s = 1 / sqrtf(2);
   Case cases[3] = {{{-1.9, 0}, {0, 1.9}, Vector(-s, s, 0), .5, 1e-1}, {{0, .9}, {0, 2}, Vector(0, 1, 0), 0, 1e-6}, {{0, 2}, {0, .9}, Vector(0, 1, 0), 1, 1e-6}};

@@ -263,6 +263,28 @@ int emu_continuous_check(void *h, const double *objT7, const int *q, int nq, con
   return n;
 }
 float emu_pt_trig(int which, float x) { return which == 0 ? ptSin(x) : which == 1 ? ptCos(x) : ptAcos(x); }
+int emu_ray_cast(void *h, const double *objT7, const double *from3, const double *to3, int n_rays, float *closest) {
+  World *w = (World *)h;
+  int hits = 0, no = (int)w->off.size();
+  std::vector<Xf> T(no);
+  for (int i = 0; i < no; ++i) T[i] = xfFrom7(objT7 + 7 * i);
+  for (int i = 0; i < n_rays; ++i) {
+    const V3 from = mk((float)from3[3 * i], (float)from3[3 * i + 1], (float)from3[3 * i + 2]);
+    const V3 to = mk((float)to3[3 * i], (float)to3[3 * i + 1], (float)to3[3 * i + 2]);
+    float cl = 1.0f;
+    for (int X = 0; X < no; ++X)
+      for (int xc = 0; xc < w->cnt[X]; ++xc) {
+        Xf tx = childWorld(w, X, xc, T[X]);
+        Cvx<1> cx; load(w, w->off[X] + xc, cx);
+        float fr;
+        V3 nrm;
+        if (rayConvex(cx, tx, from, to, fr, nrm) && fr < cl) cl = fr;   // the kernel: atomicMin over all children
+      }
+    closest[i] = cl;
+    hits += cl < 1.0f;
+  }
+  return hits;
+}
 void emu_set_trig_mode(int portable) { emuTrigMode() = portable; }
 long emu_stat(int i) {
   const EmuStats &s = emuStats();

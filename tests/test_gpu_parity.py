@@ -292,6 +292,99 @@ def test_empty_and_error_paths(eng):
     assert len(rec) > 0
 
 
+# ---- RayCastCollision (bullet_collision_checker.cpp:352-360) ---------------------------------------
+def test_ray_cast_known_answers(eng):
+    from tests.test_oracle_cpu import RAY_CASES   # fractions returned by the reference's own Bullet
+    s = M.Scene()
+    b = s.add_box(.5, .5, .5)
+    s.add_object([(b, M.IDENT7)], M.GROUP_KINBODY)
+    s.finalize()
+    eng.upload_scene(s, [T(0)])
+    fr = eng.ray_cast_poses([T(0)], [c[0] for c in RAY_CASES], [c[1] for c in RAY_CASES])
+    assert fr.tolist() == [float(np.float32(c[2])) for c in RAY_CASES]
+    assert len(eng.ray_cast_poses([T(0)], np.zeros((0, 3)), np.zeros((0, 3)))) == 0       # no rays
+    with pytest.raises(ValueError):
+        eng.ray_cast_poses([T(0)], np.zeros((2, 3)), np.zeros((3, 3)))
+    # the box moved out of the way: the poses of the call count, not those of upload_scene
+    assert eng.ray_cast_poses([T(0, 5)], [(-2, 0, 0)], [(2, 0, 0)])[0] == 1.0
+
+
+def test_ray_cast_golden_fixtures_bit_exact(eng):
+    """closest hit fractions recorded from the reference's btCollisionWorld::rayTest (tests/golden/make_rays.py)"""
+    zr = np.load(os.path.join(ROOT, "tests", "golden", "rays.npz"), allow_pickle=False)
+    hits = 0
+    for path in GOLDEN:
+        z = np.load(path, allow_pickle=False)
+        tag = os.path.basename(path)[len("random_scene_"):-4]
+        s = M.scene_from_arrays({k[6:]: z[k] for k in z.files if k.startswith("scene_")})
+        eng.upload_scene(s, z["objT"])
+        for i, d in enumerate((0.0, 0.05)):
+            eng.set_contact_distance(d)
+            fr = eng.ray_cast_poses(z["objT"], zr["from_" + tag], zr["to_" + tag])
+            assert np.array_equal(fr.view(np.uint32), zr["frac_%s_%d" % (tag, i)].view(np.uint32)), "scene %s d=%g" % (tag, d)
+            hits += int((fr < 1).sum())
+    assert hits > 1000
+
+
+@pytest.mark.parametrize("seed,spread", [(600, 0.8), (601, 1.5), (602, 0.4), (603, 0.6)])
+def test_ray_cast_random_scenes_vs_oracle(eng, seed, spread):
+    """boxes, hulls, z-cylinders (odd seeds), compounds: bit-exact against the oracle, which is bit-exact against the
+    reference's rayTest (tests/test_oracle_cpu.py)"""
+    rng = np.random.default_rng(seed)
+    s, objT, robot = synth.random_scene(rng, spread=spread, n_static=8, n_robot=5, round_prob=0.3 if seed % 2 else 0.0)
+    n = 2000
+    a = rng.uniform(-1.5 * spread, 1.5 * spread, (n, 3))
+    b = rng.uniform(-1.5 * spread, 1.5 * spread, (n, 3))
+    a[:50] = objT[rng.integers(0, len(objT), 50), 4:7]
+    b[50:60] = a[50:60]
+    eng.upload_scene(s, objT)
+    w = B.oracle_world(s)
+    fr, fo = eng.ray_cast_poses(objT, a, b), w.ray_cast(objT, a, b)
+    w.close()
+    assert (fo < 1).sum() > 100 and (fo == 1).sum() > 100
+    assert np.array_equal(fr.view(np.uint32), fo.view(np.uint32))
+
+
+def test_ray_cast_fullsize_soup_through_checker(built):
+    """Config 4's world (full-body robot + 4096-hull soup) through the host mirror of the reference interface:
+    20000 rays at one configuration.  Size-independent properties + a sample against the oracle."""
+    from trajopt_amd import collision_checker as CC
+    s, rb, static_T, d = synth.config_fullbody_soup()
+    cc = CC.CreateCollisionChecker(s, static_T)
+    cc.SetRobot(rb, ignore_zero_state=False)
+    cc.SetContactDistance(d)
+    rng = np.random.default_rng(7)
+    q = synth.fullbody_trajectory(rb, rng, 100)[37]
+    cc.SetDOFValues(q)
+    n = 20000
+    a = np.column_stack([rng.uniform(-0.5, 4.0, n), rng.uniform(-1.8, 1.8, n), rng.uniform(1.5, 2.5, n)])
+    b = np.column_stack([a[:, 0] + rng.uniform(-0.5, 0.5, n), a[:, 1] + rng.uniform(-0.5, 0.5, n), rng.uniform(-1.0, 0.2, n)])
+    fr = cc.RayCastCollisions(a, b)
+    assert (fr < 1).sum() > n // 10 and (fr == 1).sum() > n // 100 and (fr >= 0).all()
+    assert np.array_equal(fr, cc.RayCastCollisions(a, b))                        # idempotent (shared scratch reset per call)
+    assert np.array_equal(fr[5000:6000], cc.RayCastCollisions(a[5000:6000], b[5000:6000]))   # rays are independent
+    for i in (int(np.argmax(fr < 1)), int(np.argmax(fr == 1))):                  # the reference's one-ray bool form
+        assert cc.RayCastCollision(a[i], b[i]) == bool(fr[i] < 1)
+    # a hit through the robot itself: from above the base link straight down through the robot
+    fk = cc.eng.forward_kinematics(q[None])[0]
+    objT = static_T.copy()
+    for i, o in enumerate(rb.link_obj):
+        if o >= 0:
+            objT[o] = fk[i]
+    w = B.oracle_world(s, cap=16)
+    idx = rng.choice(n, 300, replace=False)
+    fo = w.ray_cast(objT, a[idx], b[idx])
+    assert np.array_equal(fr[idx].view(np.uint32), fo.view(np.uint32))
+    # robot links take part (RayCastCollision has no group filter): rays aimed at link origins from 1 m above
+    tgt = np.array([objT[o, 4:7] for o in rb.link_obj if o >= 0])
+    src = tgt + np.array([0.0, 0.0, 1.0])
+    fr2 = cc.RayCastCollisions(src, tgt - np.array([0.0, 0.0, 0.5]))
+    fo2 = w.ray_cast(objT, src, tgt - np.array([0.0, 0.0, 0.5]))
+    w.close()
+    assert np.array_equal(fr2.view(np.uint32), fo2.view(np.uint32)) and (fr2 < 1).sum() >= len(tgt) // 2
+    cc.eng.close()
+
+
 def test_fullsize_soup_properties(built):
     """Config 4 (full body, 100 timesteps, 4096-hull soup, zero-state self-collision exclusions like the reference's
     AddKinBody path): too big for the scalar oracle in the test budget, so check size-independent properties and

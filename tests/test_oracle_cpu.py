@@ -93,6 +93,76 @@ def test_golden_fixtures_bit_exact(built, path, mk):
     w.close()
 
 
+# ---- RayCastCollision (bullet_collision_checker.cpp:352-360) ---------------------------------------
+RAY_CASES = [  # unit box at the origin; fractions are what the reference's own Bullet returns (oracle/_ref)
+    ((-2, 0, 0), (2, 0, 0), 0.375),                 # straight through
+    ((-2, 2, 0), (2, 2, 0), 1.0),                   # passes beside it
+    ((0, 0, 0), (2, 0, 0), 1.0),                    # starts inside: btSubsimplexConvexCast reports nothing
+    ((2, 0, 0), (3, 0, 0), 1.0),                    # points away
+    ((-2, 0, 0), (-2, 0, 0), 1.0),                  # zero length
+    ((-2, 0.3, 0.1), (2, -0.2, 0.3), 0.37474722),   # oblique: the cast stops within its 1e-4 squared-distance tolerance
+    ((-2, 0, 0), (-1.6, 0, 0), 1.0),                # ends before the box
+]
+
+
+@pytest.mark.parametrize("mk", WORLDS)
+def test_ray_cast_known_answers(built, mk):
+    s = M.Scene()
+    b = s.add_box(.5, .5, .5)
+    s.add_object([(b, M.IDENT7)], M.GROUP_KINBODY)
+    s.finalize()
+    w = mk(s)
+    fr = w.ray_cast([T(0)], [c[0] for c in RAY_CASES], [c[1] for c in RAY_CASES])
+    assert fr.tolist() == [float(np.float32(c[2])) for c in RAY_CASES]
+    w.close()
+
+
+@pytest.mark.parametrize("mk", [B.oracle_world, util.emu_world])
+def test_ray_cast_golden_fixtures_bit_exact(built, mk):
+    """tests/golden/rays.npz: closest hit fractions recorded from the reference's btCollisionWorld::rayTest
+    (tests/golden/make_rays.py) on the scenes of random_scene_*.npz."""
+    zr = np.load(os.path.join(ROOT, "tests", "golden", "rays.npz"), allow_pickle=False)
+    hits = 0
+    for path in GOLDEN:
+        z = np.load(path, allow_pickle=False)
+        tag = os.path.basename(path)[len("random_scene_"):-4]
+        s = M.scene_from_arrays({k[6:]: z[k] for k in z.files if k.startswith("scene_")})
+        w = mk(s)
+        for i, d in enumerate((0.0, 0.05)):
+            w.set_contact_distance(d)
+            fr = w.ray_cast(z["objT"], zr["from_" + tag], zr["to_" + tag])
+            assert np.array_equal(fr.view(np.uint32), zr["frac_%s_%d" % (tag, i)].view(np.uint32)), "scene %s d=%g" % (tag, d)
+            hits += int((fr < 1).sum())
+        w.close()
+    assert hits > 1000
+
+
+@pytest.mark.skipif(not B.ref_available(), reason="oracle/_ref/libref.so is only built where /root/reference exists")
+@pytest.mark.parametrize("seed", range(500, 512))
+def test_ray_cast_oracle_vs_reference_bullet(built, seed):
+    """The C restatement and the host build of the device code against the reference's rayTest, bit for bit; seeds
+    3 mod 4 hold spheres (oracle only: the device narrowphase does not take them)."""
+    rng = np.random.default_rng(seed)
+    spread = float(rng.choice([0.4, 0.8, 1.5]))
+    spheres = seed % 4 == 3
+    s, objT, robot = synth.random_scene(rng, spread=spread, round_prob=0.3 if seed % 2 else 0.0, spheres=spheres)
+    n = 300
+    a = rng.uniform(-1.5 * spread, 1.5 * spread, (n, 3))
+    b = rng.uniform(-1.5 * spread, 1.5 * spread, (n, 3))
+    a[:20] = objT[rng.integers(0, len(objT), 20), 4:7]
+    b[20:25] = a[20:25]
+    worlds = [B.ref_world(s), B.oracle_world(s)] + ([] if spheres else [util.emu_world(s)])
+    for d in (0.0, 0.05):
+        for w in worlds:
+            w.set_contact_distance(d)
+        fr = [w.ray_cast(objT, a, b) for w in worlds]
+        assert (fr[0] < 1).any()
+        for f in fr[1:]:
+            assert np.array_equal(f.view(np.uint32), fr[0].view(np.uint32))
+    for w in worlds:
+        w.close()
+
+
 @pytest.mark.skipif(not B.ref_available(), reason="oracle/_ref/libref.so is only built where /root/reference exists")
 @pytest.mark.parametrize("seed", list(range(100, 112)) + list(range(300, 308)))
 def test_oracle_vs_reference_bullet_random(built, seed):

@@ -189,7 +189,16 @@ class HIPCollisionChecker:
             collisions.append(c)
 
     def RayCastCollision(self, point1, point2):
-        raise RuntimeError("not implemented")   # SURVEY.md 8(f4) "next"
+        """bullet_collision_checker.cpp:352-360: does the segment point1 -> point2 hit anything (robot links included)
+        at the current configuration?"""
+        return bool(self.RayCastCollisions([point1], [point2])[0] < 1.0)
+
+    def RayCastCollisions(self, points1, points2):
+        """Batched form (no counterpart in the reference, which takes one ray per call): closest hit fraction per ray,
+        1 = nothing hit."""
+        if self.robot is None:
+            return self.eng.ray_cast_poses(self.static_T, points1, points2)
+        return self.eng.ray_cast(self._dofs, points1, points2)
 
     def _current_poses(self):
         T = self.static_T.copy()

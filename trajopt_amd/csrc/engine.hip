@@ -102,6 +102,8 @@ struct tohc_engine {
   // per-call buffers
   DBuf<double> d_dofs, d_linkQT, d_objQT, d_objQT1, d_grads;
   DBuf<float> d_dynXf, d_dynAabb, d_dynXf1, d_dynAabb1;
+  DBuf<float> d_rays;              // RayCastCollision: [n_rays][8]
+  DBuf<unsigned int> d_ray_closest;
   // Enqueues alternate between NLANE lanes, each with its own HIP stream and queues, so that the discrete and the
   // cast pass of one linearization (and consecutive enqueues in general) overlap on the GPU; only k_finish, which
   // appends to the shared record slab, waits for the previous enqueue's.
@@ -273,6 +275,7 @@ void tohc_destroy(tohc_engine *e) {
   (void)hipEventDestroy(e->ev0); (void)hipEventDestroy(e->ev1);
   for (auto ev : e->events) (void)hipEventDestroy(ev);
   e->d_nrec.release(); e->h_nrec.release();
+  e->d_rays.release(); e->d_ray_closest.release();
   (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -1234,6 +1237,74 @@ int tohc_continuous_check_poses(tohc_engine *e, const double *obj_T, int n_steps
   if (rc != TOHC_OK) return rc;
   const double *g = nullptr;
   return tohc_fetch(e, records, &g, n_records);
+}
+
+// RayCastCollision: pose tables of ONE set are on the device (k_fk or k_dyn_children, stream e->stream); one k_ray
+// launch, results straight into the caller's array
+static int launchRays(tohc_engine *e, const DynMap &dm, const double *from, const double *to, int n_rays, float *closest) {
+  hipStream_t s = e->stream;
+  std::vector<float> rays((size_t)n_rays * 8, 0.0f);
+  for (int i = 0; i < n_rays; ++i)
+    for (int k = 0; k < 3; ++k) {   // toBt(): double -> float (bullet_collision_checker.cpp:72-74)
+      rays[(size_t)8 * i + k] = (float)from[3 * i + k];
+      rays[(size_t)8 * i + 4 + k] = (float)to[3 * i + k];
+    }
+  std::vector<unsigned int> init((size_t)n_rays, 0x3f800000u);   // 1.0f = ClosestRayResultCallback's initial m_closestHitFraction
+  HIPCHK(upload(e->d_rays, rays, s));
+  HIPCHK(upload(e->d_ray_closest, init, s));
+  const size_t tot = (size_t)n_rays * e->n_children;
+  if (tot > 0) {
+    if ((tot + 255) / 256 > 0x7fffffffull) return fail(e, TOHC_E_CAPACITY, "ray grid too large (%zu ray x child tests)", tot);
+    RayArgs ra;
+    ra.sc = devScene(e); ra.dm = dm; ra.dynXf = e->d_dynXf.p; ra.rays = e->d_rays.p; ra.closest = e->d_ray_closest.p; ra.n_rays = n_rays;
+    hipLaunchKernelGGL(k_ray, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ra);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipMemcpyAsync(closest, e->d_ray_closest.p, (size_t)n_rays * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return TOHC_OK;
+}
+
+int tohc_ray_cast_poses(tohc_engine *e, const double *obj_T, const double *from, const double *to, int n_rays, float *closest_fraction) {
+  if (!e) return TOHC_E_INVALID;
+  if (!e->have_scene) return fail(e, TOHC_E_STATE, "upload the scene first");
+  if (!obj_T || n_rays < 0 || (n_rays > 0 && (!from || !to || !closest_fraction))) return fail(e, TOHC_E_INVALID, "null pose, ray or result pointer");
+  if (n_rays == 0) return TOHC_OK;
+  HIPCHK(hipSetDevice(e->device));
+  int rc = syncEngine(e);
+  if (rc != TOHC_OK) return rc;
+  HIPCHK(quiesce(e));
+  e->staged = false;   // the pose tables below overwrite the staged robot tables
+  hipStream_t s = e->stream;
+  const size_t nobj = e->n_objects, nch = e->n_children;
+  HIPCHK(upload(e->d_objQT, obj_T, nobj * 7, s));
+  HIPCHK(e->d_dynXf.reserve(nch * 12)); HIPCHK(e->d_dynAabb.reserve(nch * 6));
+  DynMap dm = dynMapPoses(e);
+  if (nch > 0) {
+    hipLaunchKernelGGL(k_dyn_children, dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, s, devScene(e), dm, e->d_objQT.p, 1, e->d, e->d_dynXf.p,
+                       e->d_dynAabb.p);
+    HIPCHK(hipGetLastError());
+  }
+  return launchRays(e, dm, from, to, n_rays, closest_fraction);
+}
+
+int tohc_ray_cast(tohc_engine *e, const double *dofs, const double *from, const double *to, int n_rays, float *closest_fraction) {
+  if (!e) return TOHC_E_INVALID;
+  if (!e->have_scene || !e->have_robot) return fail(e, TOHC_E_STATE, "upload the scene and the robot first");
+  if (!dofs || n_rays < 0 || (n_rays > 0 && (!from || !to || !closest_fraction))) return fail(e, TOHC_E_INVALID, "null DOF, ray or result pointer");
+  if (n_rays == 0) return TOHC_OK;
+  int rc = tohc_sync(e);
+  if (rc != TOHC_OK) return rc;
+  rc = tohc_stage_dofs(e, dofs, 1, 1);
+  if (rc != TOHC_OK) return rc;
+  hipStream_t s = e->stream;
+  DynMap dm = dynMapRobot(e);
+  hipLaunchKernelGGL(k_fk, dim3(1), dim3(64), (size_t)e->n_links * 7 * sizeof(double), s, devRobot(e), devScene(e), dm, e->d_dofs.p, 1, e->d,
+                     e->d_linkQT.p, e->d_objQT.p, e->d_dynXf.p, e->d_dynAabb.p);
+  HIPCHK(hipGetLastError());
+  e->fk_done = false;   // no enqueue may append to these one-set tables as if they were a trajectory's
+  e->staged = false;
+  return launchRays(e, dm, from, to, n_rays, closest_fraction);
 }
 
 int tohc_forward_kinematics(tohc_engine *e, const double *dofs, int n_cfg, double *link_T) {

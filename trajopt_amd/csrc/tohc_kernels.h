@@ -264,6 +264,39 @@ __global__ void k_dyn_children(DevScene sc, DynMap dm, const double *__restrict_
 }
 
 // -----------------------------------------------------------------------------------------------------------------
+// k_ray: RayCastCollision (bullet_collision_checker.cpp:352-360) for a batch of rays.  ONE LANE per (ray, convex child):
+// btCollisionWorld::rayTest visits every object (the callback's group / mask are DefaultFilter / AllFilter, the allowed-
+// pair matrix is not consulted) and every child of a compound (btCollisionWorld.cpp:554-557); the
+// ClosestRayResultCallback keeps the smallest fraction -- here an atomicMin on the bits of the (non-negative) fraction.
+// The lanes of a wavefront share the child (its vertices arrive as one broadcast load) and take consecutive rays.
+// No cull, like the oracle: Bullet's DBVT ray cull works on boxes grown by >= 3.001 d and cannot remove a hit for
+// d >= 3.4 mm (a hit needs a point of the segment within 1 cm of the shape).
+// -----------------------------------------------------------------------------------------------------------------
+struct RayArgs {
+  DevScene sc;
+  DynMap dm;
+  const float *dynXf;      // child poses of the one pose set
+  const float *rays;       // [n_rays][8]: from xyz, 0, to xyz, 0 -- already rounded to fp32 as toBt() does
+  unsigned int *closest;   // [n_rays] bits of m_closestHitFraction, preset to 1.0f
+  int n_rays;
+};
+__global__ void __launch_bounds__(256) k_ray(RayArgs ra) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)ra.n_rays * ra.sc.n_children) return;
+  const int ray = (int)(i % ra.n_rays), child = (int)(i / ra.n_rays);
+  const ChildDesc cd = ra.sc.child_desc[child];
+  Cvx<1> cx;
+  cvxLoad<1>(cx, cd.kind, mk(cd.dims[0], cd.dims[1], cd.dims[2]), ra.sc.vx, ra.sc.vy, ra.sc.vz, ra.sc.v4, cd.voff, cd.vcnt);
+  const int slot = ra.dm.child_dyn[child];
+  const Xf tx = slot >= 0 ? ldXf(ra.dynXf + (size_t)slot * 12) : ldXf(ra.sc.stat_xf + 12 * child);
+  const F4 a = reinterpret_cast<const F4 *>(ra.rays)[2 * ray], b = reinterpret_cast<const F4 *>(ra.rays)[2 * ray + 1];
+  float fr;
+  V3 nrm;
+  if (rayConvex(cx, tx, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), fr, nrm) && fr < 1.0f && fr >= 0.0f)
+    atomicMin(ra.closest + ray, __float_as_uint(fr));
+}
+
+// -----------------------------------------------------------------------------------------------------------------
 // narrowphase
 // -----------------------------------------------------------------------------------------------------------------
 struct NarrowArgs {

@@ -1696,4 +1696,54 @@ TOHC_DEV bool timeOfImpact(EpaMem *mem, const Cvx<G> &A, float discA, const Xf &
   return true;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// RayCastCollision (bullet_collision_checker.cpp:352-360): btSubsimplexConvexCast::calcTimeOfImpact
+// [btSubSimplexConvexCast.cpp:38-156] as rayTestSingleInternal calls it (btCollisionWorld.cpp:279-301).  convexA is
+// btSphereShape(0) with margin 0: its support vertex is (0,0,0) in every direction; fromA / toA are identity rotations
+// at the ray's ends (:856-859); B rests and answers through the VIRTUAL localGetSupportingVertex (margin 0).
+// ---------------------------------------------------------------------------------------------------------------
+TOHC_DEV V3 interp3(V3 a, V3 b, float rt) {  // btVector3::setInterpolate3, scalar branch (btVector3.h:494-497)
+  const float s = 1.0f - rt;
+  return mk(s * a.x + rt * b.x, s * a.y + rt * b.y, s * a.z + rt * b.z);
+}
+TOHC_DEV bool rayConvex(const Cvx<1> &B, const Xf &tB, V3 from, V3 to, float &fraction, V3 &normal) {
+  Simplex sx;
+  vssReset(sx);
+  const V3 linVelA = to - from, linVelB = tB.o - tB.o;
+  float lambda = 0.0f;
+  V3 oA = from;
+  Xf iB = tB;   // interpolatedTransB: only its origin is ever rewritten
+  const V3 r = linVelA - linVelB;
+  const V3 zero = mk(0, 0, 0);
+  V3 supA = zero + oA;
+  V3 supB = xfApply(tB, supPlainVirtual<1>(B, mulVM(r, tB.b)));
+  V3 v = supA - supB;
+  V3 n = mk(0, 0, 0);
+  float dist2 = len2(v);
+  for (int maxIter = 32; dist2 > 0.0001f && maxIter > 0; --maxIter) {   // while ((dist2 > epsilon) && maxIter--)
+    supA = zero + oA;
+    supB = xfApply(iB, supPlainVirtual<1>(B, mulVM(v, iB.b)));
+    const V3 w = supA - supB;
+    const float VdotW = dot(v, w);
+    if (lambda > 1.0f) return false;
+    if (VdotW > 0.0f) {
+      const float VdotR = dot(v, r);
+      if (VdotR >= -(FLT_EPSILON * FLT_EPSILON)) return false;
+      lambda = lambda - VdotW / VdotR;
+      oA = interp3(from, to, lambda);
+      iB.o = interp3(tB.o, tB.o, lambda);   // s*o + rt*o: not always o again in fp32
+      n = v;
+    }
+    if (!vssInSimplex(sx, w)) vssAdd(sx, w, supA, supB);
+    const bool ok = vssUpdate(sx);   // closest(v): v = m_cachedV whatever the outcome
+    v = sx.cV;
+    dist2 = ok ? len2(v) : 0.0f;
+  }
+  fraction = lambda;
+  normal = (len2(n) >= (FLT_EPSILON * FLT_EPSILON)) ? vdiv(n, len(n)) : mk(0, 0, 0);
+  if (dot(normal, r) >= -0.0f) return false;   // -result.m_allowedPenetration
+  return len2(normal) > 0.0001f;               // the acceptance test of rayTestSingleInternal (:304)
+}
+
 }  // namespace tohc

@@ -66,6 +66,8 @@ SYMBOLS = {
     "tohc_continuous_check_trajectory": (C.c_int, [C.c_void_p, _f64p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "tohc_continuous_check_poses": (C.c_int, [C.c_void_p, _f64p, C.c_int, _i32p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "tohc_forward_kinematics": (C.c_int, [C.c_void_p, _f64p, C.c_int, _f64p]),
+    "tohc_ray_cast": (C.c_int, [C.c_void_p, _f64p, _f64p, _f64p, C.c_int, C.POINTER(C.c_float)]),
+    "tohc_ray_cast_poses": (C.c_int, [C.c_void_p, _f64p, _f64p, _f64p, C.c_int, C.POINTER(C.c_float)]),
     "tohc_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "tohc_set_capacity": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64]),
 }
@@ -236,6 +238,23 @@ class Engine:
         self._chk(self.lib.tohc_continuous_check_poses(self.h, _p(obj_T, C.c_double), obj_T.shape[0], _p(q, C.c_int32), len(q),
                                                        C.byref(rec), C.byref(n)))
         return self._collect(rec, None, n, 1, True)[0]
+
+    def ray_cast(self, dofs, p_from, p_to):
+        """RayCastCollision for a batch of rays at the robot configuration `dofs` -> float32[n] closest hit fractions
+        (1 = nothing hit; the reference's bool is `< 1`)."""
+        return self._rays(self.lib.tohc_ray_cast, np.ascontiguousarray(dofs, np.float64).reshape(self.K), p_from, p_to)
+
+    def ray_cast_poses(self, obj_T, p_from, p_to):
+        return self._rays(self.lib.tohc_ray_cast_poses, np.ascontiguousarray(obj_T, np.float64).reshape(self.n_objects, 7), p_from, p_to)
+
+    def _rays(self, fn, state, p_from, p_to):
+        a = np.ascontiguousarray(p_from, np.float64).reshape(-1, 3)
+        b = np.ascontiguousarray(p_to, np.float64).reshape(-1, 3)
+        if len(a) != len(b):
+            raise ValueError("ray_cast: %d start points, %d end points" % (len(a), len(b)))
+        out = np.ones(len(a), np.float32)
+        self._chk(fn(self.h, _p(state, C.c_double), _p(a, C.c_double), _p(b, C.c_double), len(a), _p(out, C.c_float)))
+        return out
 
     def forward_kinematics(self, dofs):
         dofs = np.ascontiguousarray(dofs, np.float64).reshape(-1, self.K)

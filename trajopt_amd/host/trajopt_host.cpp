@@ -523,6 +523,21 @@ void HIPCollisionChecker::CastVsAll(Configuration& rad, const vector<KinBody::Li
   for (int i = 0; i < n; ++i) collisions.push_back(ToCollision(r[i], NULL, 0));
 }
 
+// bullet_collision_checker.cpp:352-360: UpdateBulletFromRave + rayTest with a ClosestRayResultCallback -> hasHit()
+vector<float> HIPCollisionChecker::RayCastCollisions(const vector<double>& points1, const vector<double>& points2) {
+  if (points1.size() != points2.size() || points1.size() % 3 != 0) throw std::runtime_error("RayCastCollisions: point arrays must hold the same number of xyz triples");
+  vector<float> closest(points1.size() / 3, 1.0f);
+  if (closest.empty()) return closest;
+  vector<double> T = CurrentPoses();
+  chk(tohc_ray_cast_poses(m_e, T.data(), points1.data(), points2.data(), (int)closest.size(), closest.data()));
+  ++m_engineCalls;
+  return closest;
+}
+bool HIPCollisionChecker::RayCastCollision(const OR::Vector& point1, const OR::Vector& point2) {
+  const vector<double> a = {point1.x, point1.y, point1.z}, b = {point2.x, point2.y, point2.z};
+  return RayCastCollisions(a, b)[0] < 1.0f;
+}
+
 void HIPCollisionChecker::ContinuousCheckTrajectory(const TrajArray& traj, Configuration& rad, vector<Collision>& collisions) {   // :708-753
   BindConfiguration(rad);
   if (m_obj2link.empty() || traj.rows() < 2) return;

@@ -206,7 +206,9 @@ class HIPCollisionChecker : public CollisionChecker {
                  vector<Collision>& collisions);
   void ExcludeCollisionPair(const KinBody::Link& link0, const KinBody::Link& link1);
   void IncludeCollisionPair(const KinBody::Link& link0, const KinBody::Link& link1);
-  bool RayCastCollision(const OR::Vector&, const OR::Vector&) { throw std::runtime_error("not implemented"); }
+  bool RayCastCollision(const OR::Vector& point1, const OR::Vector& point2);
+  /** Batched form (no counterpart in the reference): closest hit fraction per ray, 1 = nothing hit. points: xyz triples. */
+  vector<float> RayCastCollisions(const vector<double>& points1, const vector<double>& points2);
 
   // ---- additions (no counterpart in the reference) ----
   /** The active configuration LinksVsAll linearizes against (the evaluators call this from their constructors; CastVsAll
