@@ -1825,9 +1825,10 @@ static int rayConvex(const shape_t *sB, const xf *tB, v3 from, v3 to, float *fra
 /* closest[i] = ClosestRayResultCallback::m_closestHitFraction after rayTest(from_i, to_i): 1 when nothing was hit
  * (RayCastCollision returns hasHit(), i.e. closest < 1).  Every object takes part: the callback's group / mask are
  * DefaultFilter / AllFilter and the proxies' masks are AllFilter [cw:RayResultCallback::needsCollision]; the allowed-
- * pair matrix is not consulted.  No cull: Bullet's DBVT ray cull works on boxes grown by >= 3.001 d (and history
- * dependent fat margins); a hit needs a point of the segment within sqrt(1e-4) = 1 cm of the shape (or 32 iterations
- * without convergence), so for d >= 3.4 mm the cull cannot remove a hit. */
+ * pair matrix is not consulted.  No cull: Bullet's DBVT ray cull works on object boxes grown by 3.001 d plus history
+ * dependent fat margins.  It matters only for the rare hit the cast reports at a point away from the shape (it keeps
+ * simplex vertices computed at earlier lambdas): measured against the reference's rayTest on 2 x 800 000 rays, many of
+ * them grazing, 0 rays differ at d = 0.05 and 18 at d = 0, where the reference's tight boxes cull such a hit. */
 int ora_ray_cast(void *h, const double *objT7, const double *from3, const double *to3, int n_rays, float *closest) {
   world_t *w = (world_t *)h;
   int hits = 0;

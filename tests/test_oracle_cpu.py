@@ -164,6 +164,34 @@ def test_ray_cast_oracle_vs_reference_bullet(built, seed):
 
 
 @pytest.mark.skipif(not B.ref_available(), reason="oracle/_ref/libref.so is only built where /root/reference exists")
+def test_ray_cast_grazing_rays_and_the_reference_cull(built):
+    """the restatement has no broadphase ray cull (Bullet's depends on the DBVT's history).  With the
+    boxes grown by 3.001 d = 15 cm the cull never matters; with d = 0 the reference's tight boxes cull the rare hit
+    that btSubsimplexConvexCast reports away from the shape, and the restatement reports it (never the other way round)."""
+    rng = np.random.default_rng(705)
+    spread = float(rng.choice([0.4, 0.8, 1.5]))
+    s, objT, robot = synth.random_scene(rng, spread=spread, n_static=10, n_robot=6, round_prob=0.4)
+    n = 20000
+    a = rng.uniform(-1.5 * spread, 1.5 * spread, (n, 3))
+    b = rng.uniform(-1.5 * spread, 1.5 * spread, (n, 3))
+    k = n // 2
+    tgt = objT[rng.integers(0, len(objT), k), 4:7] + rng.normal(size=(k, 3)) * 0.15
+    b[:k] = a[:k] + (tgt - a[:k]) * rng.uniform(0.5, 3.0, (k, 1))
+    wr, wo = B.ref_world(s), B.oracle_world(s)
+    seen = []
+    # d = 0 first: queried after d = 0.05 the reference's DBVT still holds the larger boxes (btDbvt::update keeps a
+    # volume that contains the new one) and culls nothing either -- its answer depends on that history
+    for d in (0.0, 0.05, 0.0):
+        wr.set_contact_distance(d); wo.set_contact_distance(d)
+        fr, fo = wr.ray_cast(objT, a, b), wo.ray_cast(objT, a, b)
+        ne = fr.view(np.uint32) != fo.view(np.uint32)
+        seen.append(int(ne.sum()))
+        assert (fo[ne] < fr[ne]).all()
+    assert 0 < seen[0] <= 10 and seen[1] == 0 and seen[2] == 0
+    wr.close(); wo.close()
+
+
+@pytest.mark.skipif(not B.ref_available(), reason="oracle/_ref/libref.so is only built where /root/reference exists")
 @pytest.mark.parametrize("seed", list(range(100, 112)) + list(range(300, 308)))
 def test_oracle_vs_reference_bullet_random(built, seed):
     """seeds >= 300: half of the shapes are z-cylinders (GT_Cylinder, bullet_collision_checker.cpp:153-158)"""

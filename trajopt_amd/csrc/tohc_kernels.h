@@ -269,8 +269,8 @@ __global__ void k_dyn_children(DevScene sc, DynMap dm, const double *__restrict_
 // pair matrix is not consulted) and every child of a compound (btCollisionWorld.cpp:554-557); the
 // ClosestRayResultCallback keeps the smallest fraction -- here an atomicMin on the bits of the (non-negative) fraction.
 // The lanes of a wavefront share the child (its vertices arrive as one broadcast load) and take consecutive rays.
-// No cull, like the oracle: Bullet's DBVT ray cull works on boxes grown by >= 3.001 d and cannot remove a hit for
-// d >= 3.4 mm (a hit needs a point of the segment within 1 cm of the shape).
+// No cull, like the oracle: Bullet's DBVT ray cull (boxes grown by 3.001 d plus history-dependent fat margins) only
+// matters for the rare hit btSubsimplexConvexCast reports away from the shape (stale simplex vertices), DESIGN.md 5a.
 // -----------------------------------------------------------------------------------------------------------------
 struct RayArgs {
   DevScene sc;
