@@ -292,6 +292,63 @@ def test_empty_and_error_paths(eng):
     assert len(rec) > 0
 
 
+def test_engine_state_survives_failed_calls(built):
+    """A fetch before any enqueue is an empty slab; a rejected upload leaves the previous scene and robot in place
+    (same answers as before it); after a capacity overflow the truncated slab cannot be fetched or appended to; an
+    appended pass must agree with the slab on want_jacobians."""
+    from trajopt_amd import engine
+    e = engine.Engine(0)
+    try:
+        rec, _ = e.fetch()
+        assert len(rec) == 0
+        s, rb, static_T = _arm_world("rightarm", TABLE)
+        e.upload_scene(s, static_T)
+        e.upload_robot(rb)
+        e.set_contact_distance(0.2)
+        q = rb.q_robot[1:8][None]
+        ref, gref = e.links_vs_all_batch(q, 1, 1)
+        assert len(ref) > 0
+        # a second, larger scene that fails validation at its LAST object (the shapes and children before it are fine)
+        big = M.Scene()
+        for i in range(s.n_objects + 5):
+            big.add_object([(big.add_box(.1, .1, .1), M.IDENT7)], M.GROUP_KINBODY)
+        big.finalize()
+        big.arrays["obj_cnt"][-1] = 3                   # child range runs past the end
+        with pytest.raises(engine.EngineError, match="child range"):
+            e.upload_scene(big, np.tile(np.array(M.IDENT7), (big.n_objects, 1)))
+        bad = synth.pr2_like(M.Scene(), seed=0, active="rightarm")
+        bad.finalize()
+        bad.arrays["dof"][-1] = 99                      # out of range, found after the other links were read
+        with pytest.raises(engine.EngineError, match="out of range"):
+            e.upload_robot(bad)
+        rec, g = e.links_vs_all_batch(q, 1, 1)          # the first scene and robot still answer, identically
+        assert rec.tobytes() == ref.tobytes() and np.array_equal(g, gref)
+        # overflow: sync reports it, and the slab it truncated is not handed out afterwards
+        e.set_capacity(16, 4)
+        e.stage_dofs(q, 1, 1)
+        e.enqueue_links_vs_all(-1, True, append=False)
+        with pytest.raises(engine.EngineError) as ex:
+            e.sync()
+        assert ex.value.code == -3
+        with pytest.raises(engine.EngineError) as ex:
+            e.fetch()
+        assert ex.value.code == -4
+        with pytest.raises(engine.EngineError) as ex:
+            e.enqueue_cast_vs_all(1, True, append=True)
+        assert ex.value.code == -4
+        e.set_capacity(1 << 22, 1 << 18)
+        e.enqueue_links_vs_all(-1, True, append=False)
+        with pytest.raises(engine.EngineError) as ex:   # one slab, one layout
+            e.enqueue_cast_vs_all(1, False, append=True)
+        assert ex.value.code == -1
+        e.enqueue_cast_vs_all(1, True, append=True)
+        rec, g = e.fetch()
+        disc = rec[rec["cctype"] == 0]
+        assert disc.tobytes() == ref.tobytes() and g.shape == (len(rec), 2, rb.K)
+    finally:
+        e.close()
+
+
 # ---- RayCastCollision (bullet_collision_checker.cpp:352-360; SURVEY.md 8 f4) ---------------------------------------
 def test_ray_cast_known_answers(eng):
     from tests.test_oracle_cpu import RAY_CASES   # fractions returned by the reference's own Bullet

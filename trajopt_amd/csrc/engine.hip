@@ -26,9 +26,13 @@ using namespace tohc;
 // host side
 // -----------------------------------------------------------------------------------------------------------------
 template <class T>
-struct DBuf {  // grow-only device buffer
+struct DBuf {  // grow-only device buffer; released with its owner (the engine's device must be current then)
   T *p = nullptr;
   size_t cap = 0;
+  DBuf() = default;
+  DBuf(const DBuf &) = delete;
+  DBuf &operator=(const DBuf &) = delete;
+  ~DBuf() { release(); }
   hipError_t reserve(size_t n) {
     if (n <= cap) return hipSuccess;
     if (p) (void)hipFree(p);
@@ -44,6 +48,10 @@ template <class T>
 struct HBuf {  // grow-only pinned host buffer
   T *p = nullptr;
   size_t cap = 0;
+  HBuf() = default;
+  HBuf(const HBuf &) = delete;
+  HBuf &operator=(const HBuf &) = delete;
+  ~HBuf() { release(); }
   hipError_t reserve(size_t n) {
     if (n <= cap) return hipSuccess;
     if (p) (void)hipHostFree(p);
@@ -146,8 +154,11 @@ struct tohc_engine {
   HBuf<unsigned int> h_nrec;
   int staged_B = 0, staged_T = 0;
   bool staged = false;
-  bool last_robot_mode = true, last_want_jac = false;
-  size_t fetched_n = 0;
+  bool last_robot_mode = true, last_want_jac = false;   // of the current slab (set by the enqueue that starts it; appends must agree)
+  // What tohc_fetch may trust: 0 = no slab yet / a new one is being filled (pending enqueues), 1 = the last sync
+  // covered every enqueue of the slab and found no overflow, -1 = that sync failed (capacity / HIP error): *h_nrec
+  // may then exceed what d_records holds, and the slab is truncated -- fetch refuses it (TOHC_E_STATE).
+  int slab_state = 0;
   int gjk_group = 1;  // lanes per pair in k_gjk: 1 (default), 16 or 64 (TOHC_GJK_GROUP)
   int pen_group = 1;   // lanes per pair in k_pen: 1, or 4 (hull vertices in registers; TOHC_PEN_GROUP=4: measured no faster, GJK2's LDS bookkeeping dominates)
   int epa_block = 64;  // threads per k_epa block (TOHC_EPA_BLOCK = 16 or 64)
@@ -217,7 +228,7 @@ int tohc_create(tohc_engine **out, int device) {
   e->device = device;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess) {
-    delete e;
+    tohc_destroy(e);
     return TOHC_E_HIP;
   }
   const char *g = getenv("TOHC_GROUP");
@@ -225,11 +236,11 @@ int tohc_create(tohc_engine **out, int device) {
   if (const char *pt = getenv("TOHC_PRETEST")) e->pretest = atoi(pt) != 0;
   if (const char *ns = getenv("TOHC_STREAMS")) e->n_lanes = std::min(std::max(atoi(ns), 1), 4);
   if (const char *nc = getenv("TOHC_CHUNKS")) e->chunks = std::min(std::max(atoi(nc), 1), 4);
-  if (hipEventCreateWithFlags(&e->ev_fk, hipEventDisableTiming) != hipSuccess) { delete e; return TOHC_E_HIP; }
+  if (hipEventCreateWithFlags(&e->ev_fk, hipEventDisableTiming) != hipSuccess) { tohc_destroy(e); return TOHC_E_HIP; }
   for (auto &ln : e->lane)
     if (hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ln.done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ln.ranged, hipEventDisableTiming) != hipSuccess) {
-      delete e;
+      tohc_destroy(e);
       return TOHC_E_HIP;
     }
   if (const char *eb = getenv("TOHC_EPA_BLOCK")) e->epa_block = atoi(eb) == 16 ? 16 : 64;
@@ -240,9 +251,10 @@ int tohc_create(tohc_engine **out, int device) {
   e->breaking = (float)(2.001 * (double)e->d);
   e->events.resize((size_t)RING * NEV);
   for (auto &ev : e->events)
-    if (hipEventCreate(&ev) != hipSuccess) { delete e; return TOHC_E_HIP; }
+    if (hipEventCreate(&ev) != hipSuccess) { tohc_destroy(e); return TOHC_E_HIP; }
   if (e->d_cnt.reserve(RING) != hipSuccess || e->d_rec_base.reserve(RING) != hipSuccess || e->h_cnt.reserve(RING) != hipSuccess || e->d_nrec.reserve(1) != hipSuccess ||
-      e->h_nrec.reserve(1) != hipSuccess || hipMemset(e->d_nrec.p, 0, sizeof(unsigned int)) != hipSuccess) { delete e; return TOHC_E_HIP; }
+      e->h_nrec.reserve(1) != hipSuccess || hipMemset(e->d_nrec.p, 0, sizeof(unsigned int)) != hipSuccess) { tohc_destroy(e); return TOHC_E_HIP; }
+  *e->h_nrec.p = 0;   // a fetch before the first enqueue reads this word
   *out = e;
   return TOHC_OK;
 }
@@ -254,30 +266,15 @@ void tohc_destroy(tohc_engine *e) {
     if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
     if (ln.done) (void)hipEventDestroy(ln.done);
     if (ln.ranged) (void)hipEventDestroy(ln.ranged);
-    ln.pairs.release(); ln.epaq.release(); ln.penq.release(); ln.hits.release();
   }
   if (e->ev_fk) (void)hipEventDestroy(e->ev_fk);
-  (void)hipStreamSynchronize(e->stream);
-  DBuf<int> *ib[] = {&e->d_shape_kind, &e->d_shape_voff, &e->d_shape_vcnt, &e->d_child_shape, &e->d_child_obj, &e->d_child_idx, &e->d_obj_off,
-                     &e->d_obj_cnt, &e->d_obj_compound, &e->d_obj_group, &e->d_parent, &e->d_jtype, &e->d_dof, &e->d_dof_col, &e->d_link_dyn,
-                     &e->d_obj_jaclink, &e->d_obj_dynR, &e->d_child_dynR, &e->d_dyn_childrenR, &e->d_qchildrenR, &e->d_obj_dynP,
-                     &e->d_child_dynP, &e->d_dyn_childrenP, &e->d_qchildrenP};
-  for (auto b : ib) b->release();
-  DBuf<float> *fb[] = {&e->d_shape_dims, &e->d_shape_lmin, &e->d_shape_lmax, &e->d_vx, &e->d_vy, &e->d_vz, &e->d_child_localT, &e->d_stat_xf,
-                       &e->d_stat_aabb, &e->d_dynXf, &e->d_dynAabb, &e->d_dynXf1, &e->d_dynAabb1};
-  for (auto b : fb) b->release();
-  e->d_v4.release(); e->d_stat_sph.release(); e->d_cl_soaR.release(); e->d_stat_soaR.release(); e->d_stat_soaP.release();
-  DBuf<double> *db[] = {&e->d_T_origin, &e->d_axis, &e->d_mult, &e->d_offs, &e->d_q_robot, &e->d_dofs, &e->d_linkQT, &e->d_objQT, &e->d_objQT1, &e->d_grads};
-  for (auto b : db) b->release();
-  e->d_allowed.release(); e->d_dbg.release(); e->d_cnt.release(); e->d_rec_base.release(); e->d_records.release();
-  e->d_sorted.release(); e->d_gsorted.release(); e->d_sort_keys.release(); e->d_sort_idx.release(); e->d_sort_tmp.release();
-  e->h_records.release(); e->h_sorted.release(); e->h_grads.release(); e->h_gsorted.release(); e->h_cnt.release();
-  (void)hipEventDestroy(e->ev0); (void)hipEventDestroy(e->ev1);
-  for (auto ev : e->events) (void)hipEventDestroy(ev);
-  e->d_nrec.release(); e->h_nrec.release();
-  e->d_rays.release(); e->d_ray_closest.release();
-  (void)hipStreamDestroy(e->stream);
-  delete e;
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (e->ev0) (void)hipEventDestroy(e->ev0);
+  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  for (auto ev : e->events)
+    if (ev) (void)hipEventDestroy(ev);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;   // every DBuf / HBuf releases its memory in its destructor: the list cannot drift from the struct
 }
 
 const char *tohc_last_error(const tohc_engine *e) { return e ? e->err.c_str() : "null engine"; }
@@ -392,8 +389,42 @@ int tohc_upload_scene(tohc_engine *e, int n_shapes, const int32_t *shape_kind, c
   if (n_shapes <= 0 || n_children <= 0 || n_objects <= 0 || !shape_kind || !shape_param || !child_shape || !child_T || !obj_child_off ||
       !obj_child_cnt || !obj_compound || !obj_group || !obj_static_T)
     return fail(e, TOHC_E_INVALID, "upload_scene: null or empty input");
+  // Validate EVERYTHING before the engine is touched: a rejected upload leaves the previous scene (host tables, device
+  // buffers, have_scene / have_robot) exactly as it was.
+  for (int i = 0; i < n_shapes; ++i) {
+    const float *p = shape_param + 4 * i;
+    if (shape_kind[i] == TOHC_BOX) {
+      if (!(p[0] > 0 && p[1] > 0 && p[2] > 0)) return fail(e, TOHC_E_INVALID, "upload_scene: box %d has non-positive extents", i);
+    } else if (shape_kind[i] == TOHC_CYLZ) {
+      if (!(p[0] > 0 && p[1] > 0)) return fail(e, TOHC_E_INVALID, "upload_scene: cylinder %d has a non-positive radius or height", i);
+    } else if (shape_kind[i] == TOHC_HULL) {
+      if (!shape_voff || !shape_vcnt || !vx || !vy || !vz || shape_vcnt[i] < 1 || shape_vcnt[i] > 64 || shape_voff[i] < 0 ||
+          (int64_t)shape_voff[i] + shape_vcnt[i] > n_verts)
+        return fail(e, TOHC_E_INVALID, "upload_scene: hull %d has a bad vertex range (1..64 vertices supported)", i);
+    } else {
+      return fail(e, TOHC_E_UNSUPPORTED, "upload_scene: shape %d has kind %d; boxes, z-cylinders and convex hulls are supported (spheres: Bullet's sphere-specific algorithms are not restated)", i, shape_kind[i]);
+    }
+  }
+  for (int c = 0; c < n_children; ++c)
+    if (child_shape[c] < 0 || child_shape[c] >= n_shapes) return fail(e, TOHC_E_INVALID, "upload_scene: child %d references shape %d", c, child_shape[c]);
+  {
+    std::vector<char> owned(n_children, 0);
+    for (int o = 0; o < n_objects; ++o) {
+      if (obj_child_off[o] < 0 || obj_child_cnt[o] < 1 || (int64_t)obj_child_off[o] + obj_child_cnt[o] > n_children)
+        return fail(e, TOHC_E_INVALID, "upload_scene: object %d has a bad child range", o);
+      if (!obj_compound[o] && obj_child_cnt[o] != 1) return fail(e, TOHC_E_INVALID, "upload_scene: bare convex object %d must have one child", o);
+      for (int k = 0; k < obj_child_cnt[o]; ++k) {
+        if (owned[obj_child_off[o] + k]) return fail(e, TOHC_E_INVALID, "upload_scene: child %d belongs to two objects", obj_child_off[o] + k);
+        owned[obj_child_off[o] + k] = 1;
+      }
+    }
+    for (int c = 0; c < n_children; ++c)
+      if (!owned[c]) return fail(e, TOHC_E_INVALID, "upload_scene: child %d belongs to no object", c);
+  }
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(quiesce(e));
+  // from here on only HIP calls can fail; until the last of them has succeeded the engine has no scene
+  e->have_scene = e->have_robot = e->staged = false;
   e->n_shapes = n_shapes; e->n_children = n_children; e->n_objects = n_objects; e->n_verts = n_verts;
   e->h_shape_kind.assign(shape_kind, shape_kind + n_shapes);
   e->h_shape_voff.assign(n_shapes, 0); e->h_shape_vcnt.assign(n_shapes, 0);
@@ -403,7 +434,6 @@ int tohc_upload_scene(tohc_engine *e, int n_shapes, const int32_t *shape_kind, c
     if (shape_kind[i] == TOHC_BOX) {
       // btBoxShape ctor (setSafeMargin; dims = h - margin) followed by the checker's setMargin(0): (dims + margin) - 0
       // (btBoxShape.cpp:17-26, btBoxShape.h:87-96, bullet_collision_checker.cpp:227,244)
-      if (!(p[0] > 0 && p[1] > 0 && p[2] > 0)) return fail(e, TOHC_E_INVALID, "upload_scene: box %d has non-positive extents", i);
       float m = safeMargin(0.04f, p[0], p[1], p[2]);
       for (int k = 0; k < 3; ++k) {
         float dim = ((p[k] * 1.0f - m) + m) - 0.0f;
@@ -411,17 +441,14 @@ int tohc_upload_scene(tohc_engine *e, int n_shapes, const int32_t *shape_kind, c
       }
     } else if (shape_kind[i] == TOHC_CYLZ) {
       // btCylinderShapeZ(r, r, h/2): same margin round trip as the box (btCylinderShape.cpp:18-27); param = (radius, half height)
-      if (!(p[0] > 0 && p[1] > 0)) return fail(e, TOHC_E_INVALID, "upload_scene: cylinder %d has a non-positive radius or height", i);
       const float he[3] = {p[0], p[0], p[1]};
       float m = safeMargin(0.04f, he[0], he[1], he[2]);
       for (int k = 0; k < 3; ++k) {
         float dim = ((he[k] * 1.0f - m) + m) - 0.0f;
         e->h_shape_dims[3 * i + k] = dim; e->h_shape_lmin[3 * i + k] = -dim; e->h_shape_lmax[3 * i + k] = dim;
       }
-    } else if (shape_kind[i] == TOHC_HULL) {
+    } else {   // TOHC_HULL (validated above)
       int off = shape_voff[i], cnt = shape_vcnt[i];
-      if (!vx || !vy || !vz || cnt < 1 || cnt > 64 || off < 0 || off + cnt > n_verts)
-        return fail(e, TOHC_E_INVALID, "upload_scene: hull %d has a bad vertex range (1..64 vertices supported)", i);
       e->h_shape_voff[i] = off; e->h_shape_vcnt[i] = cnt;
       float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
       for (int k = 0; k < cnt; ++k) {
@@ -429,8 +456,6 @@ int tohc_upload_scene(tohc_engine *e, int n_shapes, const int32_t *shape_kind, c
         for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], q[a]); hi[a] = fmaxf(hi[a], q[a]); }
       }
       for (int a = 0; a < 3; ++a) { e->h_shape_lmin[3 * i + a] = lo[a]; e->h_shape_lmax[3 * i + a] = hi[a]; }
-    } else {
-      return fail(e, TOHC_E_UNSUPPORTED, "upload_scene: shape %d has kind %d; boxes, z-cylinders and convex hulls are supported (spheres: Bullet's sphere-specific algorithms are not restated)", i, shape_kind[i]);
     }
   }
   // bounding sphere of every shape about the centre of its local box (k_broadphase's first pre-test stage); the radius
@@ -454,32 +479,25 @@ int tohc_upload_scene(tohc_engine *e, int n_shapes, const int32_t *shape_kind, c
   e->h_child_shape.assign(child_shape, child_shape + n_children);
   e->h_child_obj.assign(n_children, -1); e->h_child_idx.assign(n_children, 0);
   e->h_child_localT.assign((size_t)n_children * 12, 0.f);
-  for (int c = 0; c < n_children; ++c) {
-    if (child_shape[c] < 0 || child_shape[c] >= n_shapes) return fail(e, TOHC_E_INVALID, "upload_scene: child %d references shape %d", c, child_shape[c]);
-    stXf(&e->h_child_localT[12 * c], xfFrom7(child_T + 7 * c));
-  }
+  for (int c = 0; c < n_children; ++c) stXf(&e->h_child_localT[12 * c], xfFrom7(child_T + 7 * c));
   e->h_obj_off.assign(obj_child_off, obj_child_off + n_objects); e->h_obj_cnt.assign(obj_child_cnt, obj_child_cnt + n_objects);
   e->children_in_object_order = true;
   for (int o = 0, run = 0; o < n_objects; ++o) { e->children_in_object_order &= obj_child_off[o] == run; run += obj_child_cnt[o]; }
   e->h_obj_compound.assign(obj_compound, obj_compound + n_objects); e->h_obj_group.assign(obj_group, obj_group + n_objects);
   e->h_obj_static_T.assign(obj_static_T, obj_static_T + (size_t)7 * n_objects);
-  for (int o = 0; o < n_objects; ++o) {
-    if (obj_child_off[o] < 0 || obj_child_cnt[o] < 1 || obj_child_off[o] + obj_child_cnt[o] > n_children)
-      return fail(e, TOHC_E_INVALID, "upload_scene: object %d has a bad child range", o);
-    if (!obj_compound[o] && obj_child_cnt[o] != 1) return fail(e, TOHC_E_INVALID, "upload_scene: bare convex object %d must have one child", o);
+  for (int o = 0; o < n_objects; ++o)
     for (int k = 0; k < obj_child_cnt[o]; ++k) {
       e->h_child_obj[obj_child_off[o] + k] = o;
       e->h_child_idx[obj_child_off[o] + k] = k;
     }
-  }
-  for (int c = 0; c < n_children; ++c)
-    if (e->h_child_obj[c] < 0) return fail(e, TOHC_E_INVALID, "upload_scene: child %d belongs to no object", c);
   e->h_allowed.assign((size_t)n_objects * n_objects, 1);
   // "poses" mode: every object moves
   e->h_obj_dynP.resize(n_objects); std::iota(e->h_obj_dynP.begin(), e->h_obj_dynP.end(), 0);
   e->h_child_dynP.resize(n_children); std::iota(e->h_child_dynP.begin(), e->h_child_dynP.end(), 0);
   e->h_dyn_childrenP = e->h_child_dynP;
   e->h_stat_childrenR = e->h_child_dynP;   // no robot yet: nothing moves in robot mode
+  e->h_child_dynR.clear(); e->h_obj_dynR.clear(); e->h_dyn_childrenR.clear(); e->h_qchildrenR.clear();   // a previous robot's maps index the old scene
+  e->n_dyn_objR = e->n_dyn_childrenR = 0;
   e->h_stat_childrenP.clear();
   hipStream_t s = e->stream;
   HIPCHK(upload(e->d_shape_kind, e->h_shape_kind, s)); HIPCHK(upload(e->d_shape_voff, e->h_shape_voff, s)); HIPCHK(upload(e->d_shape_vcnt, e->h_shape_vcnt, s));
@@ -501,9 +519,9 @@ int tohc_upload_scene(tohc_engine *e, int n_shapes, const int32_t *shape_kind, c
   HIPCHK(upload(e->d_obj_dynP, e->h_obj_dynP, s)); HIPCHK(upload(e->d_child_dynP, e->h_child_dynP, s)); HIPCHK(upload(e->d_dyn_childrenP, e->h_dyn_childrenP, s));
   HIPCHK(upload(e->d_stat_childrenP, std::vector<int>(1, 0), s)); HIPCHK(upload(e->d_stat_soaP, std::vector<float>(6 * 64, 0.f), s));
   HIPCHK(hipStreamSynchronize(s));
-  e->have_scene = true;
-  e->have_robot = false;
-  return refreshStatic(e);
+  const int rc = refreshStatic(e);
+  e->have_scene = rc == TOHC_OK;
+  return rc;
 }
 
 int tohc_upload_robot(tohc_engine *e, int n_links, const int32_t *parent, const int32_t *jtype, const double *T_origin, const double *axis,
@@ -515,18 +533,34 @@ int tohc_upload_robot(tohc_engine *e, int n_links, const int32_t *parent, const 
       (n_joint_inds > 0 && !joint_inds) || (n_dof > 0 && !q_robot))
     return fail(e, TOHC_E_INVALID, "upload_robot: null or empty input");
   if (affine & ~15) return fail(e, TOHC_E_UNSUPPORTED, "upload_robot: only DOF_X|DOF_Y|DOF_Z|DOF_RotationAxis affine DOFs are supported");
+  // validate first: a rejected upload leaves the previous robot in place, tables and flags untouched
+  const int newK = n_joint_inds + ((affine & 1) != 0) + ((affine & 2) != 0) + ((affine & 4) != 0) + ((affine & 8) != 0);
+  if (newK <= 0) return fail(e, TOHC_E_INVALID, "upload_robot: no active degrees of freedom");
+  {
+    std::vector<char> taken(e->n_objects, 0);
+    for (int i = 0; i < n_links; ++i) {
+      if (parent[i] >= i || parent[i] < -1) return fail(e, TOHC_E_INVALID, "upload_robot: link %d: parents must precede children", i);
+      if (dof[i] >= n_dof) return fail(e, TOHC_E_INVALID, "upload_robot: link %d: dof %d out of range", i, dof[i]);
+      if (jtype[i] != TOHC_J_FIXED && jtype[i] != TOHC_J_REVOLUTE && jtype[i] != TOHC_J_PRISMATIC)
+        return fail(e, TOHC_E_INVALID, "upload_robot: link %d: unknown joint type %d", i, jtype[i]);
+      if (link_obj[i] >= e->n_objects) return fail(e, TOHC_E_INVALID, "upload_robot: link %d: object %d out of range", i, link_obj[i]);
+      if (link_obj[i] >= 0) {
+        if (taken[link_obj[i]]) return fail(e, TOHC_E_INVALID, "upload_robot: object %d is attached to two links", link_obj[i]);
+        taken[link_obj[i]] = 1;
+      }
+    }
+    for (int a = 0; a < n_joint_inds; ++a)
+      if (joint_inds[a] < 0 || joint_inds[a] >= n_dof) return fail(e, TOHC_E_INVALID, "upload_robot: joint_inds[%d] = %d out of range", a, joint_inds[a]);
+  }
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(quiesce(e));
+  e->have_robot = e->staged = false;   // until the last HIP call below has succeeded
   e->n_links = n_links; e->n_joint_inds = n_joint_inds; e->affine = affine; e->n_dof = n_dof;
-  e->K = n_joint_inds + ((affine & 1) != 0) + ((affine & 2) != 0) + ((affine & 4) != 0) + ((affine & 8) != 0);
-  if (e->K <= 0) return fail(e, TOHC_E_INVALID, "upload_robot: no active degrees of freedom");
+  e->K = newK;
   e->h_parent.assign(parent, parent + n_links); e->h_jtype.assign(jtype, jtype + n_links); e->h_dof.assign(dof, dof + n_links);
   e->h_link_obj.assign(link_obj, link_obj + n_links);
   e->h_dof_col.assign(n_links, -1);
   for (int i = 0; i < n_links; ++i) {
-    if (parent[i] >= i) return fail(e, TOHC_E_INVALID, "upload_robot: link %d: parents must precede children", i);
-    if (dof[i] >= n_dof) return fail(e, TOHC_E_INVALID, "upload_robot: link %d: dof %d out of range", i, dof[i]);
-    if (link_obj[i] >= e->n_objects) return fail(e, TOHC_E_INVALID, "upload_robot: link %d: object %d out of range", i, link_obj[i]);
     if (jtype[i] != TOHC_J_FIXED && dof[i] >= 0)
       for (int a = 0; a < n_joint_inds; ++a)
         if (joint_inds[a] == dof[i]) { e->h_dof_col[i] = a; break; }
@@ -541,7 +575,6 @@ int tohc_upload_robot(tohc_engine *e, int n_links, const int32_t *parent, const 
   for (int i = 0; i < n_links; ++i) {
     int o = link_obj[i];
     if (o < 0) continue;
-    if (e->h_obj_dynR[o] >= 0) return fail(e, TOHC_E_INVALID, "upload_robot: object %d is attached to two links", o);
     e->h_obj_dynR[o] = nd; e->h_link_dyn[i] = nd; ++nd;
     bool affected = affine > 0;
     for (int j = i; j >= 0 && !affected; j = parent[j])
@@ -590,8 +623,9 @@ int tohc_upload_robot(tohc_engine *e, int n_links, const int32_t *parent, const 
   HIPCHK(upload(e->d_dyn_childrenR, e->h_dyn_childrenR, s)); e->h_qinfoR = queryInfo(e, e->h_qchildrenR, e->h_child_dynR);
   HIPCHK(upload(e->d_qchildrenR, e->h_qinfoR, s));
   HIPCHK(hipStreamSynchronize(s));
-  e->have_robot = true;
-  return refreshStatic(e);
+  const int rc = refreshStatic(e);
+  e->have_robot = rc == TOHC_OK;
+  return rc;
 }
 
 int tohc_set_allowed_matrix(tohc_engine *e, int n_objects, const uint8_t *allowed) {
@@ -680,7 +714,7 @@ static DynMap dynMapPoses(tohc_engine *e) {
 // -----------------------------------------------------------------------------------------------------------------
 // stage -> enqueue -> sync -> fetch.  The one-shot batch calls are exactly these four in a row.
 // -----------------------------------------------------------------------------------------------------------------
-static int syncEngine(tohc_engine *e) {
+static int syncEngineImpl(tohc_engine *e) {
   hipStream_t s = e->stream;
   for (auto &ln : e->lane) HIPCHK(hipStreamSynchronize(ln.stream));
   if (e->pending.empty()) { HIPCHK(hipStreamSynchronize(s)); return TOHC_OK; }
@@ -738,6 +772,14 @@ static int syncEngine(tohc_engine *e) {
   return TOHC_OK;
 }
 
+static int syncEngine(tohc_engine *e) {
+  const bool had = !e->pending.empty();
+  const int rc = syncEngineImpl(e);
+  if (rc != TOHC_OK) { e->slab_state = -1; e->pending.clear(); }   // overflow or a HIP error: nothing of this slab may be fetched
+  else if (had) e->slab_state = 1;
+  return rc;
+}
+
 static int64_t countAabbTests(const tohc_engine *e, const std::vector<int> &qchildren, const CallParams &cp) {
   // tuples the broadphase examines = units x (query child, other child) combinations that pass the object filters
   int64_t per = 0;
@@ -768,6 +810,15 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
                         bool robotMode, int slot, bool append) {
   const int nQ = (int)h_qchildren.size();
   const int K = robotMode ? e->K : 1;
+  // one slab, one layout: the enqueue that starts a slab fixes whether it carries gradient rows (and of which robot
+  // mode); an appended pass must agree, or fetch would hand out rows that were never written / drop rows that were
+  const bool wantJ = robotMode && cp.want_jac;
+  const bool noSlab = e->slab_state == 0 && e->pending.empty();
+  if (append && !noSlab) {
+    if (e->slab_state < 0) return fail(e, TOHC_E_STATE, "append: the slab this would add to overflowed (or its sync failed); start a new one");
+    if (e->last_robot_mode != robotMode || e->last_want_jac != wantJ)
+      return fail(e, TOHC_E_INVALID, "append: want_jacobians / query mode differ from the enqueue that started the slab");
+  }
   tohc_engine::Lane &ln = e->lane[slot % e->n_lanes];
   tohc_engine::Lane *prev = slot > 0 ? &e->lane[(slot - 1) % e->n_lanes] : nullptr;   // the enqueue before this one, if it is still pending
   hipStream_t s = ln.stream;
@@ -852,8 +903,8 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
   pd.slot = slot;
   pd.aabb_tests = countAabbTests(e, h_qchildren, cp);
   e->pending.push_back(pd);
-  e->last_robot_mode = robotMode;
-  e->last_want_jac = robotMode && cp.want_jac;
+  if (!append || noSlab) { e->last_robot_mode = robotMode; e->last_want_jac = wantJ; }
+  if (!append) e->slab_state = 0;   // a new slab is being filled
   e->last_T = cp.T;
   return TOHC_OK;
 }
@@ -908,6 +959,7 @@ static int launchSweep(tohc_engine *e, const DynMap &dm, const int *d_qchildren,
   e->pending.push_back(pd);
   e->last_robot_mode = robotMode;
   e->last_want_jac = false;
+  e->slab_state = 0;
   e->last_T = cp.T;
   return TOHC_OK;
 }
@@ -1013,7 +1065,9 @@ int tohc_fetch(tohc_engine *e, const tohc_record **records, const double **grads
   HIPCHK(hipSetDevice(e->device));
   int rc = syncEngine(e);
   if (rc != TOHC_OK) return rc;
-  const size_t n = *e->h_nrec.p;
+  if (e->slab_state < 0) return fail(e, TOHC_E_STATE, "fetch: the last sync of this slab failed (capacity or HIP error); there is no valid slab");
+  if (e->slab_state == 0) return TOHC_OK;   // nothing enqueued yet: an empty slab
+  const size_t n = std::min<size_t>(*e->h_nrec.p, e->d_records.cap);
   if (n == 0) return TOHC_OK;
   hipStream_t s = e->stream;
   const int K = e->last_robot_mode ? e->K : 1;
