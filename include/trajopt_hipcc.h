@@ -169,6 +169,20 @@ int tohc_ray_cast(tohc_engine *e, const double *dofs, const double *from, const 
 /* the same on explicit poses: obj_T [n_objects][7] */
 int tohc_ray_cast_poses(tohc_engine *e, const double *obj_T, const double *from, const double *to, int n_rays, float *closest_fraction);
 
+/* NO COUNTERPART IN THE REFERENCE.  tohc_ray_cast_poses for callers that cannot allocate (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc): the same kernels and the same answers, but every
+ * pointer is DEVICE memory the caller owns (d_obj_T [n_objects][7], d_from / d_to [n_rays][3] doubles,
+ * d_closest_fraction [n_rays] floats), and the working buffers (child poses, cull boxes, the fp32 ray table) live in a
+ * fixed array inside the library's device image instead of the engine's grow-only buffers: the call makes no
+ * hipMalloc / hipFree / allocating library call.  The results are complete when it returns (it waits for its stream).
+ * Limits: the scene may hold at most TOHC_NOALLOC_MAX_CHILDREN convex geometries and a call at most
+ * TOHC_NOALLOC_MAX_RAYS rays, else TOHC_E_CAPACITY and nothing runs.  Every engine on one GPU shares that GPU's
+ * array (about 2.7 MB, held until the process ends): calls that overlap in time on one GPU race -- serialise them. */
+#define TOHC_NOALLOC_MAX_CHILDREN 8192
+#define TOHC_NOALLOC_MAX_RAYS 65536
+int tohc_ray_cast_poses_noalloc(tohc_engine *e, const double *d_obj_T, const double *d_from, const double *d_to, int n_rays,
+                                float *d_closest_fraction);
+
 /* device FK only (diagnostics / tests): link_T [B*T][n_links][7] */
 int tohc_forward_kinematics(tohc_engine *e, const double *dofs, int n_cfg, double *link_T);
 

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -216,6 +217,31 @@ static float safeMargin(float cur, float x, float y, float z) {  // btConvexInte
   return safe < cur ? safe : cur;
 }
 
+// -----------------------------------------------------------------------------------------------------------------
+// Working memory of tohc_ray_cast_poses_noalloc: a fixed array in the library's device image (each GPU the library
+// runs on holds its own copy, at its own address, until the process ends).  `scratch` itself is only the host-side
+// handle of the symbol: host code asks for the device address once per device (scratchInit, from tohc_create, with that
+// device current) and uses that pointer everywhere -- kernel arguments included.
+//   layout: child poses [MAX_CHILDREN][12] fp32 | cull boxes [MAX_CHILDREN][6] fp32 | rays [MAX_RAYS][8] fp32
+// -----------------------------------------------------------------------------------------------------------------
+static const size_t SCRATCH_XF_FLOATS = (size_t)TOHC_NOALLOC_MAX_CHILDREN * 12, SCRATCH_BOX_FLOATS = (size_t)TOHC_NOALLOC_MAX_CHILDREN * 6,
+                    SCRATCH_RAY_FLOATS = (size_t)TOHC_NOALLOC_MAX_RAYS * 8;
+static __device__ __align__(256) float scratch[SCRATCH_XF_FLOATS + SCRATCH_BOX_FLOATS + SCRATCH_RAY_FLOATS];
+static const int SCRATCH_MAX_DEVICES = 64;
+static float *g_scratch_ptr[SCRATCH_MAX_DEVICES];   // device address of `scratch` on each device, null until scratchInit
+static std::mutex g_scratch_mutex;
+static hipError_t scratchInit(int device) {   // `device` is the current device
+  if (device < 0 || device >= SCRATCH_MAX_DEVICES) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_ptr[device]) return hipSuccess;
+  void *p = nullptr;
+  const hipError_t r = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+  if (r != hipSuccess) return r;
+  if (!p) return hipErrorInvalidSymbol;
+  g_scratch_ptr[device] = static_cast<float *>(p);
+  return hipSuccess;
+}
+
 extern "C" {
 
 int tohc_create(tohc_engine **out, int device) {
@@ -255,6 +281,7 @@ int tohc_create(tohc_engine **out, int device) {
   if (e->d_cnt.reserve(RING) != hipSuccess || e->d_rec_base.reserve(RING) != hipSuccess || e->h_cnt.reserve(RING) != hipSuccess || e->d_nrec.reserve(1) != hipSuccess ||
       e->h_nrec.reserve(1) != hipSuccess || hipMemset(e->d_nrec.p, 0, sizeof(unsigned int)) != hipSuccess) { tohc_destroy(e); return TOHC_E_HIP; }
   *e->h_nrec.p = 0;   // a fetch before the first enqueue reads this word
+  if (scratchInit(device) != hipSuccess) { tohc_destroy(e); return TOHC_E_HIP; }
   *out = e;
   return TOHC_OK;
 }
@@ -1340,6 +1367,41 @@ int tohc_ray_cast_poses(tohc_engine *e, const double *obj_T, const double *from,
     HIPCHK(hipGetLastError());
   }
   return launchRays(e, dm, from, to, n_rays, closest_fraction);
+}
+
+// The allocation-free variant: caller-owned DEVICE pointers in and out, working buffers in `scratch` (through the
+// per-device pointer), three kernels on the engine's stream, no hipMalloc / hipFree / allocating library call.  It does
+// not touch the engine's own pose tables or slab, so staged DOF vectors and pending enqueues are left as they are.
+int tohc_ray_cast_poses_noalloc(tohc_engine *e, const double *d_obj_T, const double *d_from, const double *d_to, int n_rays,
+                                float *d_closest_fraction) {
+  if (!e) return TOHC_E_INVALID;
+  if (!e->have_scene) return fail(e, TOHC_E_STATE, "upload the scene first");
+  if (!d_obj_T || n_rays < 0 || (n_rays > 0 && (!d_from || !d_to || !d_closest_fraction))) return fail(e, TOHC_E_INVALID, "null pose, ray or result pointer");
+  if (e->n_children > TOHC_NOALLOC_MAX_CHILDREN)
+    return fail(e, TOHC_E_CAPACITY, "ray_cast_poses_noalloc: the scene has %d convex geometries, the fixed working buffer holds %d", e->n_children,
+                TOHC_NOALLOC_MAX_CHILDREN);
+  if (n_rays > TOHC_NOALLOC_MAX_RAYS)
+    return fail(e, TOHC_E_CAPACITY, "ray_cast_poses_noalloc: %d rays in one call, the fixed working buffer holds %d", n_rays, TOHC_NOALLOC_MAX_RAYS);
+  if (n_rays == 0) return TOHC_OK;
+  HIPCHK(hipSetDevice(e->device));
+  float *sp = (e->device >= 0 && e->device < SCRATCH_MAX_DEVICES) ? g_scratch_ptr[e->device] : nullptr;
+  if (!sp) return fail(e, TOHC_E_STATE, "ray_cast_poses_noalloc: no working buffer on device %d", e->device);
+  float *xf = sp, *box = sp + SCRATCH_XF_FLOATS, *rays = box + SCRATCH_BOX_FLOATS;
+  hipStream_t s = e->stream;
+  const size_t nch = e->n_children;
+  const DynMap dm = dynMapPoses(e);
+  // every word the kernels below read from the working buffer is written by the two kernels before them in this call:
+  // nothing of an earlier call's contents is used, so nothing needs clearing
+  hipLaunchKernelGGL(k_dyn_children, dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, s, devScene(e), dm, d_obj_T, 1, e->d, xf, box);
+  hipLaunchKernelGGL(k_ray_prep, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, s, d_from, d_to, n_rays, rays,
+                     reinterpret_cast<unsigned int *>(d_closest_fraction));
+  const size_t tot = (size_t)n_rays * nch;   // <= 65536 * 8192 tests: the grid below fits
+  RayArgs ra;
+  ra.sc = devScene(e); ra.dm = dm; ra.dynXf = xf; ra.rays = rays; ra.closest = reinterpret_cast<unsigned int *>(d_closest_fraction); ra.n_rays = n_rays;
+  hipLaunchKernelGGL(k_ray, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ra);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(s));
+  return TOHC_OK;
 }
 
 int tohc_ray_cast(tohc_engine *e, const double *dofs, const double *from, const double *to, int n_rays, float *closest_fraction) {

@@ -296,6 +296,21 @@ __global__ void __launch_bounds__(256) k_ray(RayArgs ra) {
     atomicMin(ra.closest + ray, __float_as_uint(fr));
 }
 
+// rays given as doubles in device memory -> the fp32 table k_ray reads (toBt(): double -> float,
+// bullet_collision_checker.cpp:72-74) + the callback's initial m_closestHitFraction = 1 (tohc_ray_cast_poses_noalloc;
+// the allocating entry points do both on the host)
+__global__ void __launch_bounds__(256) k_ray_prep(const double *__restrict__ from, const double *__restrict__ to, int n_rays, float *__restrict__ rays,
+                                                  unsigned int *__restrict__ closest) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rays) return;
+  F4 a, b;
+  a.x = (float)from[3 * i]; a.y = (float)from[3 * i + 1]; a.z = (float)from[3 * i + 2]; a.w = 0.0f;
+  b.x = (float)to[3 * i]; b.y = (float)to[3 * i + 1]; b.z = (float)to[3 * i + 2]; b.w = 0.0f;
+  reinterpret_cast<F4 *>(rays)[2 * i] = a;
+  reinterpret_cast<F4 *>(rays)[2 * i + 1] = b;
+  closest[i] = 0x3f800000u;
+}
+
 // -----------------------------------------------------------------------------------------------------------------
 // narrowphase
 // -----------------------------------------------------------------------------------------------------------------

@@ -68,6 +68,7 @@ SYMBOLS = {
     "tohc_forward_kinematics": (C.c_int, [C.c_void_p, _f64p, C.c_int, _f64p]),
     "tohc_ray_cast": (C.c_int, [C.c_void_p, _f64p, _f64p, _f64p, C.c_int, C.POINTER(C.c_float)]),
     "tohc_ray_cast_poses": (C.c_int, [C.c_void_p, _f64p, _f64p, _f64p, C.c_int, C.POINTER(C.c_float)]),
+    "tohc_ray_cast_poses_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),   # device pointers
     "tohc_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "tohc_set_capacity": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64]),
 }
@@ -246,6 +247,10 @@ class Engine:
 
     def ray_cast_poses(self, obj_T, p_from, p_to):
         return self._rays(self.lib.tohc_ray_cast_poses, np.ascontiguousarray(obj_T, np.float64).reshape(self.n_objects, 7), p_from, p_to)
+
+    def ray_cast_poses_noalloc(self, d_obj_T, d_from, d_to, n_rays, d_out):
+        """The allocation-free variant: every argument is a DEVICE address (int) of caller-owned memory."""
+        self._chk(self.lib.tohc_ray_cast_poses_noalloc(self.h, C.c_void_p(d_obj_T), C.c_void_p(d_from), C.c_void_p(d_to), int(n_rays), C.c_void_p(d_out)))
 
     def _rays(self, fn, state, p_from, p_to):
         a = np.ascontiguousarray(p_from, np.float64).reshape(-1, 3)
