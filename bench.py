@@ -1,20 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- collision-cost linearization throughput on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W [--config fullbody|multistart]
 
-Workload (config.workload): BASELINE.json configs[3] -- full-body PR2-like robot (K=18), 100 timesteps, against a
-4096-hull convex soup, d = 0.09 -- batched as `problems_per_gpu` independent multi-start trajectories per GPU
-(configs[4]'s sharding: problems are partitioned over ranks, no data-path collective).  One STEP = one SQP
-linearization of every problem on the rank: the discrete collision cost (100 terms, self collision included) and the
-cast collision cost (99 swept terms), contacts + gradient rows, into one device slab -- FK, broadphase, GJK, EPA and
-the Jacobian epilogue all inside the timed region; the DOF vectors are already resident in HBM (tohc_stage_dofs).
-`value` = pair-evals of all ranks / max-over-ranks wall time.  The PCIe-inclusive API rate (stage + enqueue + fetch to
-pinned host memory, canonical order) is reported beside it as `api_value`; it is never `value`.
+N > 1: started without WORLD_SIZE it launches N fresh rank processes itself (python -m torch.distributed.run, before
+anything here touches the GPU) and exits with their code; started BY torch.distributed.run (WORLD_SIZE set) it is one
+of those ranks.  One rank per GPU, problems partitioned over the ranks, no data-path collective ("scaling": "weak").
+
+Workloads (config.workload):
+  fullbody   (default) BASELINE.json configs[3] -- full-body PR2-like robot (K=18), 100 timesteps, against a 4096-hull
+             convex soup, d = 0.09 -- batched as `problems_per_gpu` (64) independent multi-start trajectories per GPU;
+  multistart BASELINE.json configs[4], one GPU's share: 1024 independent python_examples/benchmark.py-shaped problems
+             (right arm K=7, T=11, discrete + cast) in the reference's kitchen_counter world (52 boxes).
+One STEP = one SQP linearization of every problem on the rank: the discrete collision cost (self collision included)
+and the cast collision cost, contacts + gradient rows, into one device slab -- FK, broadphase, GJK, EPA and the Jacobian
+epilogue all inside the timed region; the DOF vectors are already resident in HBM (tohc_stage_dofs).
+`value` = pair-evals of all ranks / max-over-ranks wall time of a block of K steps (barrier + synchronize on both
+sides); the block is repeated until >= 1 s has been timed and the MEDIAN block is reported.  `value` stops at the
+device slab; `value_host_delivered` is the same workload through stage + enqueue + fetch (slab in canonical order in
+pinned host memory, PCIe included) -- SURVEY 8(d)'s "result delivered in host memory".  It is never `value`.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,38 +35,67 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# HBM bytes per launch from the PMC counters: profiles/r01_h_hbm_traffic_pmc.csv, collected on this workload (64
-# problems per GPU, scripts/profile_bench.sh) as MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE in separate
-# passes, bytes = (2*FETCH + WRITE) * 1024), mean of the discrete and the cast launch; "epa" = k_pen + k_epa.  Far below
-# the algorithmic bytes for the broadphase and GJK kernels because the 2 MB of hull vertices and the box table are
-# re-read from L2 / Infinity Cache, not HBM.
-TRAFFIC_BYTES_PER_LAUNCH = {"broadphase": 282.3e6, "gjk": 44.6e6, "epa": 42.7e6, "finish": 385.6e6}
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak
+CATS = {"k_broadphase": "broadphase", "k_gjk": "gjk", "k_pen": "epa", "k_epa": "epa", "k_tail_pen": "epa", "k_tail_epa": "epa",
+        "k_finish": "finish", "k_tail_finish": "finish"}
 
 
-def build_world(rank, world, problems, T=100):
-    """`problems` multi-start trajectories per GPU (weak scaling): the job's problems*world problems are numbered
-    job-wide, problem g is seeded with 1000+g, and rank r takes the block multi_gpu.partition gives it."""
-    from trajopt_amd import collision_checker as CC, multi_gpu, synth
-    s, rb, static_T, d = synth.config_fullbody_soup()
-    cc = CC.HIPCollisionChecker(s, static_T, None, device=rank_device(rank))
-    cc.SetRobot(rb)                       # uploads + IgnoreZeroStateSelfCollisions, like the reference's AddKinBody path
-    cc.SetContactDistance(d)
-    cc.eng.set_capacity(max(1 << 23, problems * (1 << 16)), max(1 << 21, problems * 40000))   # ~30 K GJK pairs / 25 K records per problem and step
-    lo, hi = multi_gpu.partition(problems * world, world, rank)
-    dofs = np.stack([synth.fullbody_trajectory(rb, np.random.default_rng(1000 + g), T) for g in range(lo, hi)])
-    return s, rb, static_T, d, cc, dofs
+# ----------------------------------------------------------------------------------------------------------------
+# launching N ranks (no GPU call, no torch import before this)
+# ----------------------------------------------------------------------------------------------------------------
+def launch_ranks(n, argv):
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd).returncode   # a child process: this one never touches the GPU
 
 
 def rank_device(rank):
     return int(os.environ.get("LOCAL_RANK", rank))
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# workloads
+# ----------------------------------------------------------------------------------------------------------------
+def build_world(config, rank, world, problems):
+    """`problems` multi-start trajectories per GPU (weak scaling): the job's problems*world problems are numbered
+    job-wide, problem g is seeded with 1000+g, and rank r takes the block multi_gpu.partition gives it."""
+    from trajopt_amd import collision_checker as CC, multi_gpu, synth
+    lo, hi = multi_gpu.partition(problems * world, world, rank)
+    if config == "multistart":
+        s, rb, static_T, d = synth.config_benchmark_scene("kitchen_counter")
+        dofs = np.concatenate([synth.benchmark_trajectories(rb, np.random.default_rng(1000 + g), 1) for g in range(lo, hi)])
+        caps = (max(1 << 22, problems * (1 << 12)), max(1 << 20, problems * 2048))
+    else:
+        s, rb, static_T, d = synth.config_fullbody_soup()
+        dofs = np.stack([synth.fullbody_trajectory(rb, np.random.default_rng(1000 + g), 100) for g in range(lo, hi)])
+        caps = (max(1 << 23, problems * (1 << 16)), max(1 << 21, problems * 40000))   # ~30 K GJK pairs / 25 K records per problem and step
+    cc = CC.HIPCollisionChecker(s, static_T, None, device=rank_device(rank))
+    cc.SetRobot(rb)                       # uploads + IgnoreZeroStateSelfCollisions, like the reference's AddKinBody path
+    cc.SetContactDistance(d)
+    cc.eng.set_capacity(*caps)
+    return s, rb, static_T, d, cc, dofs
+
+
+def workload_text(config, P, T, K):
+    if config == "multistart":
+        return ("configs[4], one GPU's share: %d independent benchmark.py-shaped problems (right arm K=%d, T=%d, discrete+cast collision "
+                "costs with gradient rows) in the reference's kitchen_counter world (52 boxes), d=0.09" % (P, K, T))
+    return ("configs[3]: full-body PR2-like (K=%d) x %d timesteps vs 4096-hull convex soup, d=0.09, discrete+cast collision costs with "
+            "gradient rows; %d independent multi-start problems per GPU" % (K, T, P))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1 only)
+# ----------------------------------------------------------------------------------------------------------------
 def cpu_baseline(s, rb, static_T, d, allowed, trajs, budget_s=12.0, only=None):
     """The CPU path on ONE host core, on a bounded sample of the same workload: timesteps of the rank's problems, each
-    problem taken with a stride of 7, problem after problem until ~budget_s of work.  kind=reference: the reference's own vendored Bullet (oracle/_ref) doing
-    LinksVsAll + CastVsAll on poses from the oracle's FK (FK / Jacobian time NOT charged to it);
-    kind=port: the C restatement doing the full linearization."""
+    problem taken with a stride of 7, problem after problem until ~budget_s of work.  kind=reference: the reference's own
+    vendored Bullet (oracle/_ref) doing LinksVsAll + CastVsAll on poses from the oracle's FK (FK / Jacobian time NOT
+    charged to it); kind=port: the C restatement doing the full linearization."""
     from oracle import bindings as B
     T = trajs.shape[1]
     order = [(p, t) for p in range(len(trajs)) for t in list(range(0, T - 1, 7)) + [t for t in range(T - 1) if t % 7]]
@@ -62,7 +103,6 @@ def cpu_baseline(s, rb, static_T, d, allowed, trajs, budget_s=12.0, only=None):
     wo = B.oracle_world(s, cap=1 << 18)
     wo.set_contact_distance(d)
     wo.set_allowed(allowed)
-    # port
     t0 = time.perf_counter()
     pe0 = wo.counter(0)
     used = 0
@@ -73,7 +113,7 @@ def cpu_baseline(s, rb, static_T, d, allowed, trajs, budget_s=12.0, only=None):
         if time.perf_counter() - t0 > budget_s / 2:   # the port is the secondary figure
             break
     dt = time.perf_counter() - t0
-    out["port"] = dict(value=(wo.counter(0) - pe0) / dt, seconds=dt, timesteps=used)
+    out["port"] = dict(value=(wo.counter(0) - pe0) / max(dt, 1e-9), seconds=dt, timesteps=used)
     if only == "port":
         wo.close()
         return out
@@ -110,31 +150,34 @@ def cpu_baseline(s, rb, static_T, d, allowed, trajs, budget_s=12.0, only=None):
     return out
 
 
-def cpu_worker(idx, n, problems, budget_s):
+def cpu_worker(idx, n, problems, budget_s, config):
     """One of the n worker processes of the all-cores CPU baseline: the same bounded sample, on the problems idx, idx+n, ..."""
-    from trajopt_amd import multi_gpu, synth
+    from trajopt_amd import synth
     from oracle import bindings as B
-    s, rb, static_T, d = synth.config_fullbody_soup()
     allowed = np.load(os.environ["BENCH_ALLOWED"])
     mine = list(range(idx, problems, n)) or [idx % problems]
-    trajs = np.stack([synth.fullbody_trajectory(rb, np.random.default_rng(1000 + g), 100) for g in mine])
+    if config == "multistart":
+        s, rb, static_T, d = synth.config_benchmark_scene("kitchen_counter")
+        trajs = np.concatenate([synth.benchmark_trajectories(rb, np.random.default_rng(1000 + g), 1) for g in mine])
+    else:
+        s, rb, static_T, d = synth.config_fullbody_soup()
+        trajs = np.stack([synth.fullbody_trajectory(rb, np.random.default_rng(1000 + g), 100) for g in mine])
     cb = cpu_baseline(s, rb, static_T, d, allowed, trajs, budget_s=budget_s, only="reference" if B.ref_available() else "port")
     k = "reference" if "reference" in cb else "port"
     print(json.dumps({"kind": k, "pair_evals": cb[k]["value"] * cb[k]["seconds"], "seconds": cb[k]["seconds"]}), flush=True)
 
 
-def cpu_baseline_all_cores(allowed, problems, budget_s=10.0):
+def cpu_baseline_all_cores(allowed, problems, config, budget_s=10.0):
     """The same CPU path on every host core the job may use (the box gives a one-GPU job 16): independent worker
     processes (children started with subprocess, each its own interpreter; none touches the GPU), one per core, each
     over its own problems for ~budget_s; rate = summed pair-evals / longest worker time."""
-    import subprocess
     import tempfile
     n = max(1, min(16, len(os.sched_getaffinity(0))))
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "allowed.npy")
         np.save(path, allowed)
         env = dict(os.environ, BENCH_ALLOWED=path, OMP_NUM_THREADS="1")
-        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i), str(n), str(problems), str(budget_s)],
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i), str(n), str(problems), str(budget_s), config],
                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for i in range(n)]
         outs = [p.communicate(timeout=180)[0] for p in procs]
     res = [json.loads(o.strip().splitlines()[-1]) for o, p in zip(outs, procs) if p.returncode == 0 and o.strip()]
@@ -143,44 +186,122 @@ def cpu_baseline_all_cores(allowed, problems, budget_s=10.0):
     return {"value": sum(r["pair_evals"] for r in res) / max(r["seconds"] for r in res), "cores": len(res), "kind": res[0]["kind"]}
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# numbers that only a profiler pass can give (HBM traffic from FETCH_SIZE / WRITE_SIZE, VALU busy, occupancy): read from
+# the newest committed summary under profiles/ (made by scripts/profile_bench.sh on this workload), never typed in
+# ----------------------------------------------------------------------------------------------------------------
+def profile_numbers(config):
+    want = "_ms_" if config == "multistart" else "_fb_"
+    def newest(suffix):
+        fs = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*" + suffix)) if "rays" not in f and want in os.path.basename(f))
+        return fs[-1] if fs else None
+    out = {}
+    f = newest("_hbm_traffic_pmc.csv")
+    if f:
+        for row in csv.DictReader(open(f)):
+            for kn, cat in CATS.items():
+                if "tohc::" + kn + "<" in row["kernel"] or "tohc::" + kn + "(" in row["kernel"]:
+                    d = out.setdefault(cat, {})
+                    d.setdefault("_tb", []).append((float(row["hbm_bytes_per_launch"]), int(row["launches"]), kn))
+        out["traffic_source"] = os.path.relpath(f, ROOT)
+    f = newest("_sq_pmc.csv")
+    if f:
+        for row in csv.DictReader(open(f)):
+            for kn, cat in CATS.items():
+                if ("tohc::" + kn + "<" in row["kernel"] or "tohc::" + kn + "(" in row["kernel"]) and row.get("valu_busy"):
+                    d = out.setdefault(cat, {})
+                    d.setdefault("_sq", []).append((float(row["valu_busy"]), float(row["waves_per_simd"]), float(row["avg_duration_ns"]) * int(row["launches"]), kn))
+        out["valu_source"] = os.path.relpath(f, ROOT)
+    for cat, d in out.items():
+        if not isinstance(d, dict):
+            continue
+        if "_tb" in d:   # bytes per launch of the category: kernels of one category run once each per pass (k_pen + k_epa add up)
+            per_kernel = {}
+            for b, n, kn in d.pop("_tb"):
+                per_kernel.setdefault(kn, []).append((b, n))
+            d["traffic"] = sum(sum(b * n for b, n in v) / max(sum(n for _, n in v), 1) for v in per_kernel.values())
+        if "_sq" in d:   # time-weighted
+            sq = d.pop("_sq")
+            w = sum(x[2] for x in sq) or 1.0
+            d["valu_busy"] = sum(x[0] * x[2] for x in sq) / w
+            d["waves_per_simd"] = sum(x[1] * x[2] for x in sq) / w
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def dry_run(args, world, rank):
+    """No GPU: the rank set-up, the partition and the reductions of the real run over gloo, with a stub in place of the
+    engine (CPU test of `--gpus N`)."""
+    import torch.distributed as dist
+    from trajopt_amd import multi_gpu
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = multi_gpu.partition(args.problems_per_gpu * world, world, rank)
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (1 + rank))
+    dt = time.perf_counter() - t0
+    units = (hi - lo) * 1000.0 * args.steps
+    dt_max, units_all = multi_gpu.reduce_measurement(dt, units, dist if world > 1 else None)
+    if rank == 0:
+        print(json.dumps({"metric": "signed-distance+Jacobian pair-evals/s (node)", "value": units_all / dt_max, "unit": "pair-evals/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "DRY RUN (no GPU, stub engine)", "problems_per_gpu": args.problems_per_gpu},
+                          "dry_run": True, "units_all_ranks": units_all}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
-        cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]))
-        return
+        cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]), sys.argv[6] if len(sys.argv) > 6 else "fullbody")
+        return 0
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--problems-per-gpu", type=int, default=64)
+    ap.add_argument("--config", choices=["fullbody", "multistart"], default="fullbody")
+    ap.add_argument("--problems-per-gpu", type=int, default=None, help="default: 64 (fullbody), 1024 (multistart)")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K-step block until this much has been timed; the median block is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hot-path-only", action="store_true",
-                    help="skip the side measurements (API rate, single-problem latency, ContinuousCheckTrajectory) so that every launch "
-                         "a profiler sees belongs to the timed workload: the command the profiles/ summaries are made with")
+                    help="skip the side measurements (host-delivered rate, single-problem latency, ContinuousCheckTrajectory) so that every "
+                         "launch a profiler sees belongs to the timed workload: the command the profiles/ summaries are made with")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: rank set-up, partition and reductions over gloo with a stub engine")
     args = ap.parse_args()
-
-    import torch
+    if args.problems_per_gpu is None:
+        args.problems_per_gpu = 1024 if args.config == "multistart" else 64
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus, sys.argv[1:])          # before any torch / GPU call in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        return 2
+    if args.dry_run:
+        dry_run(args, world, rank)
+        return 0
+
+    import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(rank_device(rank))
         dist.init_process_group("nccl", device_id=torch.device("cuda", rank_device(rank)))
     assert torch.cuda.is_available(), "bench.py needs a GPU: the engine has no CPU fallback"
+    from trajopt_amd import multi_gpu
 
-    P, T = args.problems_per_gpu, 100
-    s, rb, static_T, d, cc, dofs = build_world(rank, world, P, T)
+    P = args.problems_per_gpu
+    s, rb, static_T, d, cc, dofs = build_world(args.config, rank, world, P)
+    T = dofs.shape[1]
     eng = cc.eng
 
-    cast_first = os.environ.get("BENCH_CAST_FIRST", "0") == "1"   # timing experiment: which pass is enqueued first
-
     def step():
-        if cast_first:
-            eng.enqueue_cast_vs_all(1, True, append=False)
-            eng.enqueue_links_vs_all(-1, True, append=True)
-        else:
-            eng.enqueue_links_vs_all(-1, True, append=False)
-            eng.enqueue_cast_vs_all(1, True, append=True)
+        eng.enqueue_links_vs_all(-1, True, append=False)
+        eng.enqueue_cast_vs_all(1, True, append=True)
         eng.sync()
 
     def barrier():
@@ -188,43 +309,54 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def block():
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        return time.perf_counter() - t0
+
     eng.stage_dofs(dofs, P, T)
     for _ in range(args.warmup):
         step()
     c0 = eng.counters()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    blocks = []          # (max-over-ranks seconds, pair-evals of all ranks) of each K-step block
+    total = 0.0
+    while True:
+        ca = eng.counters()
+        dt = block()
+        cb_ = eng.counters()
+        dt_max, pairs_all = multi_gpu.reduce_measurement(dt, cb_["cum_pair_evals"] - ca["cum_pair_evals"], dist, device="cuda")
+        blocks.append((dt_max, pairs_all))
+        total += dt_max
+        if total >= args.min_seconds or len(blocks) >= 200:   # dt_max is the same on every rank: all ranks stop together
+            break
     c1 = eng.counters()
     rec, grads = eng.fetch()
-
-    pair_evals = c1["cum_pair_evals"] - c0["cum_pair_evals"]
-    from trajopt_amd import multi_gpu
-    dt_max, pairs_all = multi_gpu.reduce_measurement(dt, pair_evals, dist, device="cuda")
+    blocks.sort(key=lambda b: b[0])
+    dt_max, pairs_all = blocks[len(blocks) // 2]
+    n_steps_all = args.steps * len(blocks)
 
     # The north-star's one exchange step, AFTER the path and outside `value`: every rank's result slab of one step to
-    # every rank (RCCL all-gather over xGMI; padded fixed-size slabs), so a single SQP host can read all of them.
+    # every rank (RCCL all-gather over xGMI, device buffers in and out), so a single SQP host can read all of them.
     gather_ms = gather_bytes = None
     if dist is not None:
-        multi_gpu.all_gather_slabs(rec[:1024], grads[:1024], dist, device="cuda")   # warm-up (communicator set-up)
+        multi_gpu.all_gather_slabs_device(eng, dist)   # warm-up (communicator set-up)
         barrier()
         tg = time.perf_counter()
-        recs_all, _ = multi_gpu.all_gather_slabs(rec, grads, dist, device="cuda")
+        counts, _, _ = multi_gpu.all_gather_slabs_device(eng, dist)
         barrier()
         gather_ms = (time.perf_counter() - tg) * 1e3
-        gather_bytes = int(sum(len(r) for r in recs_all) * (152 + 16 * rb.K))
-        assert len(recs_all) == world and len(recs_all[rank]) == len(rec)
+        gather_bytes = int(counts.sum() * (152 + 16 * rb.K))
+        assert len(counts) == world and counts[rank] == len(rec)
 
-    # PCIe-inclusive API rate on rank 0's data (never `value`)
+    # host-delivered rate on rank 0's data (never `value`)
     api = lat_ms = lat_dev_ms = sweep_ms = n_sw = None
     if rank == 0 and not args.hot_path_only:
         ta = time.perf_counter()
-        n_api = 3
         pe = 0
-        for _ in range(n_api):
+        for _ in range(3):
             eng.stage_dofs(dofs, P, T)
             eng.enqueue_links_vs_all(-1, True, append=False)
             eng.enqueue_cast_vs_all(1, True, append=True)
@@ -251,36 +383,52 @@ def main():
         sweep_ms = float(np.median(sw))
 
     if rank == 0:
-        launches = c1["cum_launches"] - c0["cum_launches"]
-        ms = {k: (c1["cum_ms_" + k] - c0["cum_ms_" + k]) / max(launches, 1) for k in ("fk", "children", "broadphase", "gjk", "epa", "finish")}
-        # roofline: ALGORITHMIC bytes per launch of each kernel / its HIP-event duration;
-        # the entry for the kernel with the longest duration is reported as `roofline`.
-        #   shape side = 12 B per hull vertex (a box: its 3 half extents), pose = 48 B (fp32 3x4), cull box = 24 B
+        dc = {k: c1[k] - c0[k] for k in c1 if k.startswith("cum_")}
+        L = max(dc["cum_launches"], 1)            # passes (a step has two: discrete, cast)
+        S = max(n_steps_all, 1)
+        ms = {k: dc["cum_ms_" + k] / L for k in ("fk", "broadphase", "gjk", "epa", "finish")}   # per pass
         a = s.arrays
-        child_v = np.where(a["kind"][a["child_shape"]] == 1, a["vcnt"][a["child_shape"]], 1)
+        child_v = np.where(a["kind"][a["child_shape"]] == 1, a["vcnt"][a["child_shape"]], 8)   # vertices a support query scans (box: 8 corners' worth)
         objs, _ = rb.affected_links()
         qch = np.concatenate([np.arange(a["obj_off"][o], a["obj_off"][o] + a["obj_cnt"][o]) for o in objs])
         n_q = float(child_v[qch].mean())
-        n_x = float(child_v.mean())       # dominated by the 4096 soup children
-        L = max(launches, 1)
-        pairs_l = pair_evals / L
-        gjk_l = (c1["cum_gjk_evals"] - c0["cum_gjk_evals"]) / L
-        epa_l = (c1["cum_epa_evals"] - c0["cum_epa_evals"]) / L
-        hits_l = c1["contacts"] / 2.0     # the slab of one step holds both launches
-        units_l = P * (T - 0.5) * len(qch)  # (unit, query child) wavefronts per launch, mean of the discrete and the cast pass
+        n_x = float(child_v.mean())
+        pairs_l, gjk_l, epa_l = dc["cum_pair_evals"] / L, dc["cum_gjk_evals"] / L, dc["cum_epa_evals"] / L
+        it_l, ps_l, es_l = dc["cum_gjk_iters"] / L, dc["cum_pen_supports"] / L, dc["cum_epa_supports"] / L
+        hits_l = c1["contacts"] / 2.0             # the slab of one step holds both passes
+        units_l = P * (T - 0.5) * len(qch)        # (unit, query child) wavefronts per pass, mean of the discrete and the cast pass
+        # ---- ALGORITHMIC bytes per pass: shape side = 12 B per hull vertex, pose = 48 B, cull box = 24 B
         side = lambda nv: 12.0 * nv + 48.0
-        alg = {
-            # every pair evaluation reads the other child's box, shape and pose; each wavefront its query child's
+        alg_b = {
             "broadphase": pairs_l * (24.0 + side(n_x)) + units_l * (24.0 + side(n_q)) + gjk_l * 16.0,
             "gjk": gjk_l * (16.0 + side(n_q) + side(n_x)) + hits_l * 32.0 + epa_l * 36.0,
             "epa": epa_l * (36.0 + side(n_q) + side(n_x) + 32.0),
-            "finish": hits_l * (32.0 + 16.0 + 2 * 7 * 8.0 * 8 + 152.0 + 16.0 * rb.K),   # hit + pair + two link chains (~8 fp64 poses) + record + gradient rows
+            "finish": hits_l * (32.0 + 16.0 + 2 * 7 * 8.0 * 8 + 152.0 + 16.0 * rb.K),
         }
-        roof_all = {k: {"algorithmic_bytes_per_launch": alg[k], "ms_per_launch": ms[k],
-                        "achieved_GBs": (alg[k] / (ms[k] * 1e-3) / 1e9 if ms[k] > 0 else 0.0)} for k in alg}
-        dom = max(alg, key=lambda k: ms[k])
-        achieved = roof_all[dom]["achieved_GBs"]
+        # ---- ALGORITHMIC flops per pass: iterations x (5 (nA + nB) + 200); the swept side of a cast pair
+        # scans 2 nA + 30; half of the passes are cast => the query side costs 1.5 nq + 15 on average.  The pre-test is one
+        # support query of the query child per pair evaluation (+ ~60 flops of sphere arithmetic), the box scan 6 compares
+        # per box examined; EPA: 60 flops per face made (~3 per iteration); Jacobian epilogue 12 K per contact side, cast twice.
+        nqa = 1.5 * n_q + 15.0
+        alg_f = {
+            "broadphase": pairs_l * (5.0 * nqa + 60.0) + gjk_l * 5.0 * n_x + units_l * 64 * 12.0,
+            "gjk": it_l * (5.0 * (nqa + n_x) + 200.0),
+            "epa": (ps_l + es_l) * (5.0 * (nqa + n_x) + 100.0) + es_l * 3 * 60.0,
+            "finish": hits_l * (1.5 * 2 * 12.0 * rb.K + 0.5 * 4 * 2 * n_q * 5.0),
+        }
+        prof = profile_numbers(args.config)
+        roof_all = {}
+        for k in alg_b:
+            t = ms[k] * 1e-3
+            roof_all[k] = {"ms_per_pass": ms[k], "algorithmic_bytes_per_pass": alg_b[k], "algorithmic_flops_per_pass": alg_f[k],
+                           "achieved_GBs": alg_b[k] / t / 1e9 if t > 0 else 0.0, "achieved_TFLOPs": alg_f[k] / t / 1e12 if t > 0 else 0.0,
+                           "hbm_traffic_bytes_per_pass": prof.get(k, {}).get("traffic"), "valu_busy": prof.get(k, {}).get("valu_busy"),
+                           "waves_per_simd": prof.get(k, {}).get("waves_per_simd")}
+        dom = max(alg_b, key=lambda k: ms[k])
         kname = {"broadphase": "k_broadphase", "gjk": "k_gjk", "epa": "k_pen+k_epa", "finish": "k_finish"}[dom]
+        step_s = dt_max / args.steps
+        step_flops = 2 * sum(alg_f.values())
+        step_bytes = 2 * sum(alg_b.values())
         out = {
             "metric": "signed-distance+Jacobian pair-evals/s (node)",
             "value": pairs_all / dt_max,
@@ -288,31 +436,47 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt_max / args.steps * 1e3,
+            "ms_per_step": step_s * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "configs[3]: full-body PR2-like (K=18) x 100 timesteps vs 4096-hull convex soup, d=0.09, "
-                                   "discrete+cast collision costs with gradient rows; %d independent multi-start problems per GPU" % P,
-                       "problems_per_gpu": P, "timesteps": T, "K": rb.K, "parallelism": "problems sharded over %d GPU(s), no collective" % world},
-            "pair_evals_per_step_per_gpu": pair_evals / args.steps,
-            "gjk_evals_per_step_per_gpu": (c1["cum_gjk_evals"] - c0["cum_gjk_evals"]) / args.steps,
-            "epa_evals_per_step_per_gpu": (c1["cum_epa_evals"] - c0["cum_epa_evals"]) / args.steps,
+            "config": {"workload": workload_text(args.config, P, T, rb.K), "problems_per_gpu": P, "timesteps": T, "K": rb.K,
+                       "parallelism": "problems sharded over %d GPU(s), no collective" % world},
+            "value_scope": "device slab complete (tohc_sync); no D2H, no canonical order -- see value_host_delivered",
+            "value_host_delivered": api,
+            "timed": {"blocks": len(blocks), "seconds_total": total, "block_seconds_min_median_max": [blocks[0][0], dt_max, blocks[-1][0]]},
+            "pair_evals_per_step_per_gpu": dc["cum_pair_evals"] / S,
+            "gjk_evals_per_step_per_gpu": dc["cum_gjk_evals"] / S,
+            "epa_evals_per_step_per_gpu": dc["cum_epa_evals"] / S,
             "contacts_per_step_per_gpu": int(c1["contacts"]),
+            "mean_gjk_iterations_per_gjk_eval": dc["cum_gjk_iters"] / max(dc["cum_gjk_evals"], 1),
+            "mean_support_queries_per_penetration_eval": (dc["cum_pen_supports"] + dc["cum_epa_supports"]) / max(dc["cum_epa_evals"], 1),
+            "mean_hull_vertices": {"query_children": n_q, "all_children": n_x},
             "ms_per_sqp_linearization_single_problem_host_delivered": lat_ms,
             "ms_per_sqp_linearization_single_problem_device": lat_dev_ms,
-            "api_value": api,
             "allgather_slabs_ms": gather_ms, "allgather_slabs_bytes": gather_bytes,
             "ms_continuous_check_trajectory_single_problem": sweep_ms,
             "continuous_check_hits_single_problem": n_sw,
-            "kernel_ms_per_launch": ms,
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(dom),
-                         "note": "dominant kernel by HIP-event duration; dependent-latency bound (LDS / L2 round trips of an "
-                                 "iterative fp32 algorithm), far below the HBM roof by nature; bytes are compulsory only (SURVEY 8d)"},
+            "kernel_ms_per_pass": ms,
+            "roofline": {
+                "bound": "valu-latency", "kernel": kname,
+                "achieved": roof_all[dom]["achieved_TFLOPs"], "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": roof_all[dom]["achieved_TFLOPs"] / VALU_PEAK_TFLOPS,
+                "traffic": roof_all[dom]["hbm_traffic_bytes_per_pass"], "traffic_source": prof.get("traffic_source"),
+                "valu_busy": roof_all[dom]["valu_busy"], "waves_per_simd": roof_all[dom]["waves_per_simd"], "valu_source": prof.get("valu_source"),
+                "hbm": {"achieved": roof_all[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roof_all[dom]["achieved_GBs"] / HBM_PEAK_GBS,
+                        "note": "algorithmic bytes / kernel time: a CACHE-fed rate (hulls and box tables are re-read from L2 / Infinity "
+                                "Cache; counter traffic is ~0.1x the algorithmic bytes), not an HBM fraction"},
+                "whole_step": {"TFLOPs": step_flops / step_s / 1e12, "frac_valu": step_flops / step_s / 1e12 / VALU_PEAK_TFLOPS,
+                               "GBs": step_bytes / step_s / 1e9, "frac_hbm": step_bytes / step_s / 1e9 / HBM_PEAK_GBS},
+                "note": "dominant kernel by HIP-event duration.  The path is an iterative fp32 algorithm on <= 64-vertex hulls: bound by "
+                        "VALU issue under divergence and by dependent L2 / LDS round trips, far below both the vector-flop and the HBM roof; "
+                        "achieved = SURVEY 8(d) algorithmic flops (measured iteration counts) / kernel time."},
             "roofline_all": roof_all,
+            "fk_jacobian_parity": "unpinned against OpenRAVE (absent from the image and the reference holds no fixture): the gradient half "
+                                  "of the metric is checked against the build's own fp64 FK model, finite differences and closed forms",
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 at N = 1 only
             cb = cpu_baseline(s, rb, static_T, d, cc.allowed, dofs)
@@ -322,7 +486,7 @@ def main():
                                              % (cb[kind]["timesteps"], cb[kind]["seconds"]),
                                    "port_value": cb["port"]["value"]}
             try:   # the same on every host core of the job (north-star: "timed on the box's host cores, with the core count stated")
-                out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(cc.allowed, P)
+                out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(cc.allowed, P, args.config)
             except Exception as ex:   # a reported extra: never fails the bench
                 out["cpu_baseline"]["all_cores"] = {"error": str(ex)[:200]}
         print(json.dumps(out), flush=True)
@@ -330,7 +494,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     cc.eng.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

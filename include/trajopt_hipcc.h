@@ -73,7 +73,12 @@ typedef struct tohc_counters {
   /* pair evaluations the separating-axis pre-test inside the broadphase kernel could not finish ("farther than d")
    * and that therefore ran the iterative GJK; gjk_evals <= pair_evals */
   int64_t gjk_evals, cum_gjk_evals;
-  double cum_ms_finish; /* k_finish (cast classification, records, gradient rows); cum_ms_epa is k_epa alone */
+  double cum_ms_finish; /* k_finish (cast classification, records, gradient rows); cum_ms_epa is k_pen + k_epa */
+  /* work done, for the flop side of the roofline: passes of the GJK loop body in k_gjk (each one
+   * Minkowski support query = one hull scan per side), and support queries of the penetration solver (GJK2 and the
+   * Distance fall-back in k_pen; EPA iterations and EncloseOrigin in k_epa).  Since the last sync / cumulative. */
+  int64_t gjk_iters, pen_supports, epa_supports;
+  int64_t cum_gjk_iters, cum_pen_supports, cum_epa_supports;
 } tohc_counters;
 
 /* replaces CreateCollisionChecker(env)                       src/trajopt/bullet_collision_checker.cpp:1036-1039 */
@@ -136,6 +141,12 @@ int tohc_enqueue_links_vs_all(tohc_engine *e, int filter_mask, int want_jacobian
 int tohc_enqueue_cast_vs_all(tohc_engine *e, int gap, int want_jacobians, int append);
 int tohc_sync(tohc_engine *e);
 int tohc_fetch(tohc_engine *e, const tohc_record **records, const double **grads, int *n_records);
+
+/* tohc_fetch without the copy to the host: the slab in canonical order as it lies in DEVICE memory (d_grads rows of
+ * *row_doubles = 2K doubles, or null / 0 without gradient rows), valid until the next enqueue on this handle.  For the
+ * north-star's one exchange step -- the RCCL all-gather of every GPU's linearizations -- which takes
+ * device buffers: no round trip through host memory.  No counterpart in the reference (single process, no GPU). */
+int tohc_fetch_device(tohc_engine *e, const tohc_record **d_records, const double **d_grads, int *n_records, int *row_doubles);
 
 /* replaces LinksVsAll / CastVsAll on explicit poses (no robot model needed): the reference reads poses from the
  * OpenRAVE environment at call time (UpdateBulletFromRave, bullet_collision_checker.cpp:648-653).

@@ -145,3 +145,50 @@ def test_mimic_joint_falls_back_to_column_walk(built):
         w.close()
     finally:
         e.close()
+
+
+def test_fetch_device_and_device_all_gather(built):
+    """tohc_fetch_device hands out the slab in canonical order as it lies in device memory -- the same bytes tohc_fetch
+    copies to the host -- and multi_gpu.all_gather_slabs_device feeds it to RCCL without a trip through host memory
+    (here a one-rank `nccl` group on the one GPU; the two-rank exchange itself is tested over gloo on the CPU)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from trajopt_amd import engine, multi_gpu
+    s, rb, static_T = _world()
+    Bp, Tt = 2, 20
+    dofs = np.stack([synth.fullbody_trajectory(rb, np.random.default_rng(70 + b), Tt) for b in range(Bp)])
+    e = engine.Engine(0)
+    try:
+        e.upload_scene(s, static_T)
+        e.upload_robot(rb)
+        e.set_contact_distance(0.09)
+        e.stage_dofs(dofs, Bp, Tt)
+        e.enqueue_links_vs_all(-1, True, append=False)
+        e.enqueue_cast_vs_all(1, True, append=True)
+        d_rec, d_g, n, rowd = e.fetch_device()
+        rec, g = e.fetch()
+        assert n == len(rec) > 100 and rowd == 2 * rb.K and d_rec and d_g
+        dev = torch.device("cuda", 0)
+        got = torch.as_tensor(multi_gpu._DeviceBytes(d_rec, n * 152), device=dev).cpu().numpy()
+        assert got.tobytes() == rec.tobytes()
+        gotg = torch.as_tensor(multi_gpu._DeviceBytes(d_g, n * rowd * 8), device=dev).cpu().numpy()
+        assert gotg.tobytes() == np.ascontiguousarray(g).tobytes()
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+        try:
+            counts, recs, grads = multi_gpu.all_gather_slabs_device(e, dist)
+            assert counts.tolist() == [n] and recs.is_cuda and grads.is_cuda
+            assert recs[0, :n].cpu().numpy().tobytes() == rec.tobytes()
+            assert np.array_equal(grads[0, :n].cpu().numpy().reshape(n, 2, rb.K), g)
+        finally:
+            dist.destroy_process_group()
+        # without gradient rows the device slab has none either
+        e.enqueue_links_vs_all(-1, False, append=False)
+        _, d_g0, n0, rowd0 = e.fetch_device()
+        assert n0 > 0 and d_g0 == 0 and rowd0 == 0
+    finally:
+        e.close()

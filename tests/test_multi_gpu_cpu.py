@@ -116,3 +116,24 @@ def test_two_gloo_ranks_shard_the_problems():
             src = got[r][3]
             assert g[8][r][0] == [m[0] for m in src] and g[8][r][1] == [m[7] for m in src]
             assert g[8][r][2] == b"".join(m[8] for m in src)
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE starts two rank processes itself (torch.distributed.run, before any
+    GPU call); rank 0 prints the one JSON line with n_gpus = 2 and the job-wide unit count.  --dry-run: gloo and a stub
+    engine, so this runs without a GPU.  A WORLD_SIZE that contradicts --gpus is refused."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--problems-per-gpu", "5"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dry_run"] and out["scaling"] == "weak"
+    assert out["units_all_ranks"] == 2 * 5 * 1000.0 * 3           # both ranks' blocks of 5 problems took part
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=dict(env, WORLD_SIZE="3", RANK="0"),
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr

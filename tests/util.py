@@ -105,27 +105,10 @@ def read_host_unit_dump(path):
 
 
 def add_ref_scene(scene, name):
-    """One of the reference's obstacle worlds (tests/golden/ref_scenes.json, made by tests/golden/make_scenes.py from
-    data/*.env.xml): one static KinBody link per box, the box geometry at its own transform inside the link -- so, like
-    in the reference, every such link is a compound of one child (bullet_collision_checker.cpp:224-250)."""
-    import json
-    from trajopt_amd import model as M
-    with open(os.path.join(ROOT, "tests", "golden", "ref_scenes.json")) as f:
-        boxes = json.load(f)[name]
-    ids = []
-    for b in boxes:
-        T = tuple(b["quat"]) + tuple(b["translation"])
-        ids.append(scene.add_object([(scene.add_box(*b["extents"]), T)], M.GROUP_KINBODY, name=b["name"]))
-    return ids
+    from trajopt_amd import synth
+    return synth.add_ref_scene(scene, name)
 
 
 def benchmark_trajectories(rb, rng, n, T=11):
-    """python_examples/benchmark.py:25-30,76-77,116-118 shape: right-arm problems, straight line from a start posture to a
-    joint target drawn within +-1 rad of it (the reference takes IK solutions of a grid of hand poses; IK needs
-    OpenRAVE), T = 11 waypoints."""
     from trajopt_amd import synth
-    out = []
-    for _ in range(n):
-        q0 = rb.q_robot[1:8] + rng.uniform(-0.4, 0.4, size=7)
-        out.append(synth.straight_line(q0, q0 + rng.uniform(-1.0, 1.0, size=7), T))
-    return np.stack(out)
+    return synth.benchmark_trajectories(rb, rng, n, T)

@@ -160,6 +160,7 @@ struct tohc_engine {
   // covered every enqueue of the slab and found no overflow, -1 = that sync failed (capacity / HIP error): *h_nrec
   // may then exceed what d_records holds, and the slab is truncated -- fetch refuses it (TOHC_E_STATE).
   int slab_state = 0;
+  bool sorted_valid = false;   // d_sorted / d_gsorted hold the current slab in canonical order
   int gjk_group = 1;  // lanes per pair in k_gjk: 1 (default), 16 or 64 (TOHC_GJK_GROUP)
   int pen_group = 1;   // lanes per pair in k_pen: 1, or 4 (hull vertices in registers; TOHC_PEN_GROUP=4: measured no faster, GJK2's LDS bookkeeping dominates)
   int epa_block = 64;  // threads per k_epa block (TOHC_EPA_BLOCK = 16 or 64)
@@ -753,17 +754,22 @@ static int syncEngineImpl(tohc_engine *e) {
   unsigned int worst_pairs = 0;
   tohc_counters &c = e->counters;
   c.aabb_tests = c.pair_evals = c.epa_evals = c.gjk_evals = 0;
+  c.gjk_iters = c.pen_supports = c.epa_supports = 0;
   c.ms_last_call = 0;
   for (const auto &pd : e->pending) {
     const Counters &k = e->h_cnt.p[pd.slot];
     const unsigned int segCap = (unsigned int)(e->max_pairs / TOHC_NSHARD);
     unsigned int np = 0, ne = 0, ng = 0;
+    int64_t gi = 0, ps = 0, es = 0;
     overflow |= k.overflow != 0;
     for (int sh = 0; sh < TOHC_NSHARD; ++sh) {
       const CounterShard &cs = k.sh[sh];
       overflow |= cs.n_pairs > segCap || cs.n_epa > segCap || cs.n_hits > segCap || cs.n_pen > segCap / TOHC_PEN_DIV;
       np += cs.n_cand; ng += cs.n_pairs; ne += cs.n_epa;
+      gi += cs.n_gjk_steps; ps += cs.n_pen_sups; es += cs.n_epa_sups;
     }
+    c.gjk_iters += gi; c.pen_supports += ps; c.epa_supports += es;
+    c.cum_gjk_iters += gi; c.cum_pen_supports += ps; c.cum_epa_supports += es;
     worst_pairs = std::max(worst_pairs, ng);
     c.aabb_tests += pd.aabb_tests; c.pair_evals += np; c.epa_evals += ne; c.gjk_evals += ng;
     c.cum_aabb_tests += pd.aabb_tests; c.cum_pair_evals += np; c.cum_epa_evals += ne; c.cum_gjk_evals += ng;
@@ -930,6 +936,7 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
   pd.slot = slot;
   pd.aabb_tests = countAabbTests(e, h_qchildren, cp);
   e->pending.push_back(pd);
+  e->sorted_valid = false;
   if (!append || noSlab) { e->last_robot_mode = robotMode; e->last_want_jac = wantJ; }
   if (!append) e->slab_state = 0;   // a new slab is being filled
   e->last_T = cp.T;
@@ -987,6 +994,7 @@ static int launchSweep(tohc_engine *e, const DynMap &dm, const int *d_qchildren,
   e->last_robot_mode = robotMode;
   e->last_want_jac = false;
   e->slab_state = 0;
+  e->sorted_valid = false;
   e->last_T = cp.T;
   return TOHC_OK;
 }
@@ -1083,38 +1091,57 @@ int tohc_sync(tohc_engine *e) {
   return syncEngine(e);
 }
 
-int tohc_fetch(tohc_engine *e, const tohc_record **records, const double **grads, int *n_records) {
-  if (!e) return TOHC_E_INVALID;
-  if (!n_records) return fail(e, TOHC_E_INVALID, "n_records is null");
-  *n_records = 0;
-  if (records) *records = nullptr;
-  if (grads) *grads = nullptr;
+// sync, check that there is a slab to hand out, and -- where the 64-bit key can hold the scene -- put it in canonical
+// order ON THE DEVICE (d_sorted / d_gsorted).  *n = records, *devSorted = whether the device copies are in order.
+static int prepareSlab(tohc_engine *e, size_t *n_out, bool *devSorted) {
+  *n_out = 0;
+  *devSorted = false;
   HIPCHK(hipSetDevice(e->device));
   int rc = syncEngine(e);
   if (rc != TOHC_OK) return rc;
   if (e->slab_state < 0) return fail(e, TOHC_E_STATE, "fetch: the last sync of this slab failed (capacity or HIP error); there is no valid slab");
   if (e->slab_state == 0) return TOHC_OK;   // nothing enqueued yet: an empty slab
   const size_t n = std::min<size_t>(*e->h_nrec.p, e->d_records.cap);
+  *n_out = n;
   if (n == 0) return TOHC_OK;
+  const int K = e->last_robot_mode ? e->K : 1;
+  const bool haveG = e->last_want_jac;
+  // canonical order: Bullet's own order follows DBVT traversal and is history dependent (SURVEY.md 7).
+  // discrete records (cctype none) sort before cast records of the same (problem, t) when both were appended.
+  const bool devSort = !e->host_sort && e->last_sets <= SORT_MAX_SETS && e->n_children <= SORT_MAX_CHILDREN && e->children_in_object_order;
+  if (!devSort) return TOHC_OK;
+  if (e->sorted_valid) { *devSorted = true; return TOHC_OK; }   // this slab has been ordered already (fetch after fetch_device)
+  size_t tmpBytes = 0;
+  HIPCHK(sortTempBytes(n, &tmpBytes));
+  HIPCHK(e->d_sort_tmp.reserve(tmpBytes)); HIPCHK(e->d_sort_keys.reserve(2 * n)); HIPCHK(e->d_sort_idx.reserve(2 * n));
+  HIPCHK(e->d_sorted.reserve(n));
+  if (haveG) HIPCHK(e->d_gsorted.reserve(n * 2 * K));
+  HIPCHK(sortRecords(e->d_records.p, haveG ? e->d_grads.p : nullptr, n, e->last_T, K, e->d_obj_off.p, e->d_sort_keys.p, e->d_sort_idx.p, e->d_sort_tmp.p, tmpBytes,
+                     e->d_sorted.p, haveG ? e->d_gsorted.p : nullptr, e->stream));
+  e->sorted_valid = true;
+  *devSorted = true;
+  return TOHC_OK;
+}
+
+int tohc_fetch(tohc_engine *e, const tohc_record **records, const double **grads, int *n_records) {
+  if (!e) return TOHC_E_INVALID;
+  if (!n_records) return fail(e, TOHC_E_INVALID, "n_records is null");
+  *n_records = 0;
+  if (records) *records = nullptr;
+  if (grads) *grads = nullptr;
+  size_t n = 0;
+  bool devSort = false;
+  const bool trace = getenv("TOHC_TRACE_FETCH") != nullptr;
+  auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_a = now();
+  int rc = prepareSlab(e, &n, &devSort);
+  if (rc != TOHC_OK || n == 0) return rc;
   hipStream_t s = e->stream;
   const int K = e->last_robot_mode ? e->K : 1;
   const bool haveG = e->last_want_jac;
   HIPCHK(e->h_sorted.reserve(n));
   if (haveG) HIPCHK(e->h_gsorted.reserve(n * 2 * K));
-  // canonical order: Bullet's own order follows DBVT traversal and is history dependent (SURVEY.md 7).
-  // discrete records (cctype none) sort before cast records of the same (problem, t) when both were appended.
-  const bool trace = getenv("TOHC_TRACE_FETCH") != nullptr;
-  auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const double t_a = now();
-  const bool devSort = !e->host_sort && e->last_sets <= SORT_MAX_SETS && e->n_children <= SORT_MAX_CHILDREN && e->children_in_object_order;
   if (devSort) {
-    size_t tmpBytes = 0;
-    HIPCHK(sortTempBytes(n, &tmpBytes));
-    HIPCHK(e->d_sort_tmp.reserve(tmpBytes)); HIPCHK(e->d_sort_keys.reserve(2 * n)); HIPCHK(e->d_sort_idx.reserve(2 * n));
-    HIPCHK(e->d_sorted.reserve(n));
-    if (haveG) HIPCHK(e->d_gsorted.reserve(n * 2 * K));
-    HIPCHK(sortRecords(e->d_records.p, haveG ? e->d_grads.p : nullptr, n, e->last_T, K, e->d_obj_off.p, e->d_sort_keys.p, e->d_sort_idx.p, e->d_sort_tmp.p, tmpBytes,
-                       e->d_sorted.p, haveG ? e->d_gsorted.p : nullptr, s));
     if (trace) { HIPCHK(hipStreamSynchronize(s)); fprintf(stderr, "[fetch] device sort of %zu records: %.3f ms\n", n, now() - t_a); }
     HIPCHK(hipMemcpyAsync(e->h_sorted.p, e->d_sorted.p, n * sizeof(tohc_record), hipMemcpyDeviceToHost, s));
     if (haveG) HIPCHK(hipMemcpyAsync(e->h_gsorted.p, e->d_gsorted.p, n * 2 * K * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1152,6 +1179,27 @@ int tohc_fetch(tohc_engine *e, const tohc_record **records, const double **grads
   *n_records = (int)n;
   if (records) *records = e->h_sorted.p;
   if (grads) *grads = haveG ? e->h_gsorted.p : nullptr;
+  return TOHC_OK;
+}
+
+int tohc_fetch_device(tohc_engine *e, const tohc_record **d_records, const double **d_grads, int *n_records, int *row_doubles) {
+  if (!e) return TOHC_E_INVALID;
+  if (!n_records || !d_records) return fail(e, TOHC_E_INVALID, "null result pointer");
+  *n_records = 0;
+  *d_records = nullptr;
+  if (d_grads) *d_grads = nullptr;
+  if (row_doubles) *row_doubles = 0;
+  size_t n = 0;
+  bool devSort = false;
+  int rc = prepareSlab(e, &n, &devSort);
+  if (rc != TOHC_OK || n == 0) return rc;
+  if (!devSort) return fail(e, TOHC_E_UNSUPPORTED, "fetch_device: this slab can only be ordered on the host (more than %d pose sets or %d geometries); use tohc_fetch", SORT_MAX_SETS, SORT_MAX_CHILDREN);
+  HIPCHK(hipStreamSynchronize(e->stream));   // the caller may read the device slab on any stream
+  const int K = e->last_robot_mode ? e->K : 1;
+  *n_records = (int)n;
+  *d_records = e->d_sorted.p;
+  if (d_grads) *d_grads = e->last_want_jac ? e->d_gsorted.p : nullptr;
+  if (row_doubles) *row_doubles = e->last_want_jac ? 2 * K : 0;
   return TOHC_OK;
 }
 

@@ -90,7 +90,11 @@ struct CounterShard {
   unsigned int n_pairs, n_epa, n_hits;
   unsigned int n_pen;    // pairs k_pen hands to k_epa (origin inside the Minkowski difference)
   unsigned int n_cand;   // box-test survivors = pair evaluations; n_pairs = those the pre-test passes on to k_gjk
-  unsigned int pad[27];
+  // work done, for the flop side of the roofline (flops per pair-eval = iterations x (5 (nA + nB) + 200)):
+  unsigned int n_gjk_steps;   // passes of the GJK loop body in k_gjk (one Minkowski support query each)
+  unsigned int n_pen_sups;    // Minkowski support queries of GJK2 / the Distance fall-back in k_pen
+  unsigned int n_epa_sups;    // the same in k_epa (one per EPA iteration, plus EncloseOrigin's)
+  unsigned int pad[24];
 };
 struct Counters {
   CounterShard sh[TOHC_NSHARD];
@@ -764,6 +768,12 @@ __device__ __forceinline__ unsigned int waveSlot(unsigned int *ctr, bool want) {
   }
   return slot;
 }
+// sum of `v` over the wavefront's lanes, added to *ctr with one atomic (call with every lane of the wavefront)
+__device__ __forceinline__ void waveAdd(unsigned int *ctr, unsigned int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(ctr, v);
+}
 // Bullet's output filter [gjk:430-449] + the collector's distance filter (bullet_collision_checker.cpp:401)
 __device__ __forceinline__ bool isContact(const NarrowArgs &a, const GjkState &st, float md2, PairOut &o) {
   gjkOutput(st, md2, o);
@@ -823,6 +833,7 @@ __global__ void __launch_bounds__(BLOCK, TOHC_GJK_WAVES) k_gjk(NarrowArgs a) {
   const unsigned int runLen = min((unsigned int)TOHC_RUN, max(1u, (npairs + ngroups - 1) / ngroups));
   unsigned int run = gid * runLen, p = run, runEnd = min(run + runLen, npairs);
   unsigned int pos = 0;
+  unsigned int steps = 0;   // loop-body passes of this lane (groups: counted by their first lane)
   for (;;) {
     if (!active) {
       if (p >= runEnd) {  // this group's run is used up (or was empty): take the next one
@@ -851,6 +862,7 @@ __global__ void __launch_bounds__(BLOCK, TOHC_GJK_WAVES) k_gjk(NarrowArgs a) {
       g.init(tA, tB);
       active = true;
     }
+    if (Grp<G>::lane() == 0) ++steps;
     if (g.step(cA, cB, tA, tB, md2, maxIter)) {
       GjkState st;
       g.finish(st);
@@ -880,6 +892,7 @@ __global__ void __launch_bounds__(BLOCK, TOHC_GJK_WAVES) k_gjk(NarrowArgs a) {
       pushIfContact<G>(a, pos, sh, md2);
     }
   }
+  waveAdd(&a.cnt->sh[blockIdx.x % TOHC_NSHARD].n_gjk_steps, steps);
 }
 
 // both operands of a queued pair in their GJK roles + the GJK result so far
@@ -924,6 +937,7 @@ __global__ void __launch_bounds__(64, TOHC_PEN_WAVES) k_pen(NarrowArgs a) {
   float md2 = a.cp.breaking;
   md2 *= md2;
   const unsigned int cap2 = a.cp.seg_cap / TOHC_PEN_DIV;
+  unsigned int sups = 0;
   for (unsigned int i = gid; i < nepa; i += nlanes) {
     const EpaRec e = a.epaq[qlocate(pre, a.cp.seg_cap, i)];
     Cvx<G> A, B;
@@ -953,7 +967,9 @@ __global__ void __launch_bounds__(64, TOHC_PEN_WAVES) k_pen(NarrowArgs a) {
     if (toEpa) st.isValid = false;   // no contact yet: k_epa decides
     else gjkFinishTail(isValid2, sep, tmpA, tmpB, st);
     pushIfContact<G>(a, (unsigned int)e.pair, st, md2);
+    if (Grp<G>::lane() == 0) sups += g.nsup;
   }
+  waveAdd(&a.cnt->sh[blockIdx.x % TOHC_NSHARD].n_pen_sups, sups);
 }
 
 // k_epa: second stage (EPA proper) for the pairs k_pen handed over, one group of G lanes per pair, pools in LDS
@@ -970,6 +986,7 @@ __global__ void __launch_bounds__(BLOCK, TOHC_EPA_WAVES) k_epa(NarrowArgs a) {
   md2 *= md2;
   // Pairs are handed out on demand, BLOCK / G at a time per wavefront (a block is one wavefront or less): EPA runs take
   // from 2 to 255 iterations, and with a fixed share per group the kernel lasted as long as its unluckiest group.
+  unsigned int sups = 0;
   for (;;) {
     unsigned int first = 0;
     if (threadIdx.x == 0) first = atomicAdd(&a.cnt->epa_next, (unsigned int)groupsPerBlock);
@@ -1004,7 +1021,10 @@ __global__ void __launch_bounds__(BLOCK, TOHC_EPA_WAVES) k_epa(NarrowArgs a) {
 #endif
     gjkFinishTail(isValid2, sep, tmpA, tmpB, st);
     pushIfContact<G>(a, (unsigned int)e.pair, st, md2);
+    if (Grp<G>::lane() == 0) sups += g.nsup;
   }
+  if (BLOCK >= 64) waveAdd(&a.cnt->sh[blockIdx.x % TOHC_NSHARD].n_epa_sups, sups);
+  else if (sups) atomicAdd(&a.cnt->sh[blockIdx.x % TOHC_NSHARD].n_epa_sups, sups);
 }
 
 // point Jacobian of `link` at world point p, column k: CalculateActiveJacobian as used by PositionJacobian

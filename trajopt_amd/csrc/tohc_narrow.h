@@ -786,8 +786,10 @@ struct Gjk2 {
   unsigned rank0, rank1;  // m_simplices[0/1].rank; two scalars + selects so that the struct stays in registers
   unsigned nfree, current;
   int status;
+  unsigned nsup = 0;   // support queries so far (work counter; not part of the algorithm)
 
   TOHC_DEV void support(V3 d, unsigned sv) {  // getsupport [epa:372-376]
+    ++nsup;
     V3 dn = vdiv(d, len(d));
     st3(m->svd[sv], dn);
     st3(m->svw[sv], minkSupport<G>(shape, dn));

@@ -24,7 +24,9 @@ class Counters(C.Structure):
                 ("cum_aabb_tests", C.c_int64), ("cum_pair_evals", C.c_int64), ("cum_epa_evals", C.c_int64),
                 ("cum_launches", C.c_int64), ("cum_ms_fk", C.c_double), ("cum_ms_children", C.c_double),
                 ("cum_ms_broadphase", C.c_double), ("cum_ms_gjk", C.c_double), ("cum_ms_epa", C.c_double),
-                ("gjk_evals", C.c_int64), ("cum_gjk_evals", C.c_int64), ("cum_ms_finish", C.c_double)]
+                ("gjk_evals", C.c_int64), ("cum_gjk_evals", C.c_int64), ("cum_ms_finish", C.c_double),
+                ("gjk_iters", C.c_int64), ("pen_supports", C.c_int64), ("epa_supports", C.c_int64),
+                ("cum_gjk_iters", C.c_int64), ("cum_pen_supports", C.c_int64), ("cum_epa_supports", C.c_int64)]
 
 
 class EngineError(RuntimeError):
@@ -59,6 +61,7 @@ SYMBOLS = {
     "tohc_enqueue_cast_vs_all": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "tohc_sync": (C.c_int, [C.c_void_p]),
     "tohc_fetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(_f64p), C.POINTER(C.c_int)]),
+    "tohc_fetch_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tohc_links_vs_all_poses": (C.c_int, [C.c_void_p, _f64p, C.c_int, _i32p, C.c_int, C.c_int, C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_int)]),
     "tohc_cast_vs_all_poses": (C.c_int, [C.c_void_p, _f64p, _f64p, C.c_int, _i32p, C.c_int, C.POINTER(C.c_void_p),
@@ -206,6 +209,12 @@ class Engine:
         rec, g, n = C.c_void_p(), _f64p(), C.c_int()
         self._chk(self.lib.tohc_fetch(self.h, C.byref(rec), C.byref(g), C.byref(n)))
         return self._collect(rec, g, n, self.K, copy)
+
+    def fetch_device(self):
+        """-> (device address of the records, device address of the gradient rows or 0, n, doubles per gradient row)"""
+        rec, g, n, row = C.c_void_p(), C.c_void_p(), C.c_int(), C.c_int()
+        self._chk(self.lib.tohc_fetch_device(self.h, C.byref(rec), C.byref(g), C.byref(n), C.byref(row)))
+        return rec.value or 0, g.value or 0, n.value, row.value
 
     def links_vs_all_poses(self, obj_T, query, filter_mask=-1):
         obj_T = np.ascontiguousarray(obj_T, np.float64).reshape(-1, self.n_objects, 7)

@@ -2,8 +2,10 @@
 BASELINE.json configs[4]) partitioned over the ranks.  Computing the linearizations needs NO collective -- a rank's
 contacts and gradient rows belong to its own problems; the exchanges of the measurement are the barrier and two scalar
 reductions (max wall time, summed pair evaluations).  The one real exchange step of the north-star is optional and
-comes AFTER the path: `all_gather_slabs` returns every rank's result slab to every rank (so that a single SQP host can
-read all of them from one GPU) with one all-gather of the record counts and one all-gather of fixed-size padded slabs.
+comes AFTER the path: every rank's result slab to every rank (so that a single SQP host can read all of them from one
+GPU) with one all-gather of the record counts and one all-gather of fixed-size padded slabs.  On the GPUs
+`all_gather_slabs_device` hands the engine's DEVICE slab to RCCL as it lies (tohc_fetch_device: no trip through host
+memory); `all_gather_slabs` is the host-memory front end of the same exchange.
 Works on any torch.distributed backend: `nccl` (= RCCL over xGMI) on the GPUs, `gloo` in the CPU tests.
 """
 import numpy as np
@@ -49,31 +51,73 @@ def global_problem_ids(records, lo):
     return out
 
 
+def all_gather_padded(mine, n, dist):
+    """The exchange itself, on whatever device `mine` lives on: mine = uint8 tensor [n, row] (this rank's slab, one
+    row per record), n = its record count.  One all-gather of the counts, then ONE all-gather of the slabs padded to
+    the largest count (fixed-size messages: over xGMI every rank pushes its slab to its 7 peers on 7 distinct links).
+    -> (counts int64[world] on the host, uint8 tensor [world, nmax, row] on `mine`'s device: rank r's records are
+    out[r, :counts[r]])."""
+    import torch
+    world = dist.get_world_size()
+    counts = gather_counts(n, dist, mine.device)
+    nmax = max(int(counts.max()), 1)
+    row = mine.shape[1]
+    pad = mine
+    if mine.shape[0] != nmax:
+        pad = torch.zeros((nmax, row), dtype=torch.uint8, device=mine.device)
+        if n:
+            pad[:n] = mine[:n]                     # device-to-device
+    out = torch.empty((world * nmax, row), dtype=torch.uint8, device=mine.device)   # rank-major concatenation
+    dist.all_gather_into_tensor(out, pad.contiguous())
+    return counts, out.view(world, nmax, row)
+
+
+class _DeviceBytes:
+    """n bytes of device memory owned by someone else (the engine's slab), seen by torch without a copy."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}   # torch takes no read-only flag; nobody writes through it
+
+
+def all_gather_slabs_device(eng, dist, device_index=None):
+    """The north-star's exchange step with device buffers in and out: the engine's slab (canonical order, device memory,
+    tohc_fetch_device) goes into RCCL as it lies -- no copy to the host and back -- and every rank's records and gradient
+    rows end up on every GPU.  -> (counts[world], records uint8 tensor [world, nmax, 152], gradient rows float64 tensor
+    [world, nmax, row_doubles] or None), both on this rank's GPU; the SQP host copies out what it needs from ONE GPU."""
+    import torch
+    d_rec, d_g, n, rowd = eng.fetch_device()
+    dev = torch.device("cuda", torch.cuda.current_device() if device_index is None else device_index)
+    rec = (torch.as_tensor(_DeviceBytes(d_rec, n * 152), device=dev).view(n, 152) if n
+           else torch.zeros((0, 152), dtype=torch.uint8, device=dev))
+    counts, recs = all_gather_padded(rec, n, dist)
+    grads = None
+    if rowd:
+        g = (torch.as_tensor(_DeviceBytes(d_g, n * rowd * 8), device=dev).view(n, rowd * 8) if n
+             else torch.zeros((0, rowd * 8), dtype=torch.uint8, device=dev))
+        _, gs = all_gather_padded(g, n, dist)
+        grads = gs.view(torch.float64).view(gs.shape[0], gs.shape[1], rowd)
+    return counts, recs, grads
+
+
 def all_gather_slabs(records, grads, dist=None, device="cpu"):
-    """Every rank's (records, grads) on every rank, in rank order, problems renumbered job-wide by the caller.
-    records: numpy structured array [n] (engine.RECORD_DTYPE, 152 B); grads: float64 [n, 2, K] or None.
-    One all-gather of the counts, then ONE all-gather of a byte slab padded to the largest count (fixed-size messages:
-    over xGMI every rank pushes its slab to its 7 peers on 7 distinct links).  Returns (list of records per rank,
-    list of grads per rank)."""
+    """Host-memory front end of the same exchange (the CPU tests run it over gloo): every rank's (records, grads) on
+    every rank, in rank order, problems renumbered job-wide by the caller.  records: numpy structured array [n]
+    (engine.RECORD_DTYPE, 152 B); grads: float64 [n, 2, K] or None.  Returns (list of records per rank, list of grads
+    per rank)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return [records], [grads]
     import torch
     world = dist.get_world_size()
-    counts = gather_counts(len(records), dist, device)
-    nmax = int(counts.max())
+    n = len(records)
     rec_b = records.dtype.itemsize
     g_b = 0 if grads is None else int(np.prod(grads.shape[1:])) * 8
-    row = rec_b + g_b
-    buf = np.zeros((max(nmax, 1), row), np.uint8)
-    n = len(records)
+    buf = np.zeros((n, rec_b + g_b), np.uint8)
     if n:
-        buf[:n, :rec_b] = np.ascontiguousarray(records).view(np.uint8).reshape(n, rec_b)
+        buf[:, :rec_b] = np.ascontiguousarray(records).view(np.uint8).reshape(n, rec_b)
         if g_b:
-            buf[:n, rec_b:] = np.ascontiguousarray(grads, np.float64).view(np.uint8).reshape(n, g_b)
-    mine = torch.from_numpy(buf).to(device)
-    out = torch.empty((world * mine.shape[0], mine.shape[1]), dtype=torch.uint8, device=device)   # rank-major concatenation
-    dist.all_gather_into_tensor(out, mine)
-    host = out.cpu().numpy().reshape(world, mine.shape[0], mine.shape[1])
+            buf[:, rec_b:] = np.ascontiguousarray(grads, np.float64).view(np.uint8).reshape(n, g_b)
+    counts, out = all_gather_padded(torch.from_numpy(buf).to(device), n, dist)
+    host = out.cpu().numpy()
     recs, gs = [], []
     for r in range(world):
         c = int(counts[r])

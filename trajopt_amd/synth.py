@@ -267,3 +267,40 @@ def fullbody_trajectory(rb, rng, T=100):
     reach_l = np.array([0.3, 0.2, 0.6, -0.9, 1.0, -0.8, -1.0]) + rng.uniform(-0.3, 0.3, 7)
     q1 = np.concatenate([[0.25], reach_r, reach_l, [rng.uniform(-0.05, 0.1), rng.uniform(0.4, 0.8), rng.uniform(-0.4, 0.4)]])
     return straight_line(q0, q1, T)
+
+
+def add_ref_scene(scene, name):
+    """One of the reference's obstacle worlds (tests/golden/ref_scenes.json, made by tests/golden/make_scenes.py from
+    data/*.env.xml): one static KinBody link per box, the box geometry at its own transform inside the link -- so, like
+    in the reference, every such link is a compound of one child (bullet_collision_checker.cpp:224-250)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "ref_scenes.json")) as f:
+        boxes = json.load(f)[name]
+    ids = []
+    for b in boxes:
+        T = tuple(b["quat"]) + tuple(b["translation"])
+        ids.append(scene.add_object([(scene.add_box(*b["extents"]), T)], M.GROUP_KINBODY, name=b["name"]))
+    return ids
+
+
+def benchmark_trajectories(rb, rng, n, T=11):
+    """python_examples/benchmark.py:25-30,76-77,116-118 shape: right-arm problems, straight line from a start posture to a
+    joint target drawn within +-1 rad of it (the reference takes IK solutions of a grid of hand poses; IK needs
+    OpenRAVE), T = 11 waypoints."""
+    out = []
+    for _ in range(n):
+        q0 = rb.q_robot[1:8] + rng.uniform(-0.4, 0.4, size=7)
+        out.append(straight_line(q0, q0 + rng.uniform(-1.0, 1.0, size=7), T))
+    return np.stack(out)
+
+
+def config_benchmark_scene(name="kitchen_counter"):
+    """Configs 3 / 5: python_examples/benchmark.py-shaped right-arm problems (K = 7, T = 11, a discrete and a cast
+    collision cost, dist_pen 0.05 => d = 0.09) in one of the reference's own box worlds (kitchen_counter: 52 boxes)."""
+    s = M.Scene()
+    rb = pr2_like(s, seed=0, active="rightarm")
+    add_ref_scene(s, name)
+    s.finalize(); rb.finalize()
+    return s, rb, static_poses(s), 0.09
