@@ -2,7 +2,7 @@
 host / fall-back paths agree with the oracle.
 
   * engine variants (environment switches read by tohc_create): pre-test off, one stream, enqueues cut into unit
-    ranges on four lanes, host-side canonical sort, 16-lane-group GJK, one EPA group per wavefront;
+    ranges on four lanes, host-side canonical sort, 16-lane-group GJK, one EPA group per wavefront, two passes sharing one penetration tail;
   * several appended enqueues in one slab (the lanes' ordering events);
   * a robot with two joints on one optimisation column (mimic joint): k_finish's lane-per-column fall-back.
 """
@@ -18,7 +18,7 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 VARIANTS = [{}, {"TOHC_PRETEST": "0"}, {"TOHC_STREAMS": "1"}, {"TOHC_CHUNKS": "2", "TOHC_STREAMS": "4"}, {"TOHC_HOST_SORT": "1"},
-            {"TOHC_GJK_GROUP": "16"}, {"TOHC_EPA_BLOCK": "16"}, {"TOHC_GROUP": "64"}]
+            {"TOHC_GJK_GROUP": "16"}, {"TOHC_EPA_BLOCK": "16"}, {"TOHC_GROUP": "64"}, {"TOHC_MERGE_TAIL": "1"}]
 
 
 def _world():

@@ -1,7 +1,9 @@
 // engine.hip -- libtrajopt_hipcc.so: the C-ABI of include/trajopt_hipcc.h and the gfx950 kernels behind it.
 //
 // Pipeline of one batch call (all on the engine's own stream, nothing allocates after warm-up):
-//   k_fk -> k_broadphase -> k_gjk -> k_pen -> k_epa -> k_range -> k_finish     (kernels and layouts: tohc_kernels.h)
+//   per pass:  k_fk -> k_broadphase -> k_gjk                       (a pass = one enqueue: discrete or cast)
+//   per tail:  k_tail_pen -> k_tail_epa -> k_tail_range            (ONE launch each for all passes open at that time)
+//   per pass:  k_finish                                            (kernels and layouts: tohc_kernels.h)
 // Static obstacles are transformed once at upload (the reference re-syncs every object on every call,
 // bullet_collision_checker.cpp:629-655).  See DESIGN.md for layouts and rooflines.
 #include <hip/hip_runtime.h>
@@ -119,7 +121,7 @@ struct tohc_engine {
   struct Lane {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;       // recorded after the lane's latest k_finish
-    hipEvent_t ranged = nullptr;     // recorded after the lane's latest k_range: the next enqueue may reserve its record range
+    hipEvent_t head_done = nullptr;  // recorded after the lane's latest k_gjk: the tail may start on that pass's queues
     DBuf<PairRec> pairs;
     DBuf<EpaRec> epaq;
     DBuf<PenRec> penq;
@@ -129,6 +131,20 @@ struct tohc_engine {
   int n_lanes = 4;                   // TOHC_STREAMS=1..4
   int chunks = 1;                    // a large enqueue is cut into this many unit ranges, one per lane (TOHC_CHUNKS)
   hipEvent_t ev_fk = nullptr;        // the FK of the staged DOF vectors has finished (main stream)
+  // Passes whose head (broadphase + GJK) is on its lane and whose tail (penetration, EPA, record ranges, k_finish) is
+  // still to be launched: the tail kernels take ALL open passes in one launch each (launchTail), which is what fills
+  // the chip -- one pass alone queues fewer penetration pairs than the GPU has wave slots.  A tail goes out when
+  // max_open passes are open and, at the latest, when the host asks for results (sync / fetch) or touches the tables.
+  struct OpenHead { int slot; int lane; bool empty; NarrowArgs a; };
+  std::vector<OpenHead> open;
+  // max_open = 1 (default): every pass gets a tail of its own on its own lane.  TOHC_MERGE_TAIL=1: two passes share a
+  // tail.  Measured on config 4, 64 problems (gpurun_out/r02_d_*): the shared tail itself is shorter (1.47 vs 1.63 ms of
+  // kernel time per step) but the step is longer (4.83 vs 4.55 ms), because a shared tail cannot start before BOTH heads
+  // have finished and so no longer overlaps with the other pass's broadphase / GJK.
+  int max_open = 1;
+  hipStream_t tail_stream = nullptr;
+  hipEvent_t tail_ranged = nullptr;  // recorded after the latest k_tail_range
+  bool have_ranged = false;
   bool fk_done = false;
   DBuf<unsigned long long> d_dbg;   // TOHC_EPA_PROF builds only
   DBuf<Counters> d_cnt;            // [RING]
@@ -168,7 +184,10 @@ struct tohc_engine {
   tohc_engine() { memset(&counters, 0, sizeof counters); }
 };
 static const int RING = 32;
-static const int NEV = 7;   // events per enqueue: fk | children | broadphase | gjk | epa | finish
+// events per enqueue: [0] fk [1] (children) [2] broadphase [3] gjk [4] -- on the pass's lane; [5] tail (k_tail_pen,
+// k_tail_epa, k_tail_range) [6] -- on the tail stream, real only for the last pass of a tail, a zero-length pair for
+// the others; [7] k_finish [8] -- on the lane again
+static const int NEV = 9;
 
 static int fail(tohc_engine *e, int code, const char *fmt, ...) {
   char buf[512];
@@ -180,10 +199,13 @@ static int fail(tohc_engine *e, int code, const char *fmt, ...) {
   return code;
 }
 
+static int launchTail(tohc_engine *e);
 // nothing may still be running on the lanes when tables they read are replaced
 static hipError_t quiesce(tohc_engine *e) {
+  if (launchTail(e) != TOHC_OK) return hipErrorUnknown;   // (e->err says what failed)
   for (auto &ln : e->lane)
     if (ln.stream) { hipError_t r = hipStreamSynchronize(ln.stream); if (r != hipSuccess) return r; }
+  if (e->tail_stream) { hipError_t r = hipStreamSynchronize(e->tail_stream); if (r != hipSuccess) return r; }
   e->fk_done = false;
   return hipStreamSynchronize(e->stream);
 }
@@ -266,10 +288,15 @@ int tohc_create(tohc_engine **out, int device) {
   if (hipEventCreateWithFlags(&e->ev_fk, hipEventDisableTiming) != hipSuccess) { tohc_destroy(e); return TOHC_E_HIP; }
   for (auto &ln : e->lane)
     if (hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ln.done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ln.ranged, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&ln.head_done, hipEventDisableTiming) != hipSuccess) {
       tohc_destroy(e);
       return TOHC_E_HIP;
     }
+  if (hipStreamCreateWithFlags(&e->tail_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->tail_ranged, hipEventDisableTiming) != hipSuccess) {
+    tohc_destroy(e);
+    return TOHC_E_HIP;
+  }
+  if (const char *mt = getenv("TOHC_MERGE_TAIL")) e->max_open = atoi(mt) != 0 ? TOHC_MAX_HEADS : 1;
   if (const char *eb = getenv("TOHC_EPA_BLOCK")) e->epa_block = atoi(eb) == 16 ? 16 : 64;
   if (const char *pg = getenv("TOHC_PEN_GROUP")) e->pen_group = atoi(pg) == 4 ? 4 : 1;
   if (const char *hs = getenv("TOHC_HOST_SORT")) e->host_sort = atoi(hs) != 0;
@@ -293,8 +320,10 @@ void tohc_destroy(tohc_engine *e) {
   for (auto &ln : e->lane) {
     if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
     if (ln.done) (void)hipEventDestroy(ln.done);
-    if (ln.ranged) (void)hipEventDestroy(ln.ranged);
+    if (ln.head_done) (void)hipEventDestroy(ln.head_done);
   }
+  if (e->tail_stream) { (void)hipStreamSynchronize(e->tail_stream); (void)hipStreamDestroy(e->tail_stream); }
+  if (e->tail_ranged) (void)hipEventDestroy(e->tail_ranged);
   if (e->ev_fk) (void)hipEventDestroy(e->ev_fk);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -744,7 +773,12 @@ static DynMap dynMapPoses(tohc_engine *e) {
 // -----------------------------------------------------------------------------------------------------------------
 static int syncEngineImpl(tohc_engine *e) {
   hipStream_t s = e->stream;
+  {
+    const int rc = launchTail(e);   // passes whose tail is still to be launched
+    if (rc != TOHC_OK) return rc;
+  }
   for (auto &ln : e->lane) HIPCHK(hipStreamSynchronize(ln.stream));
+  HIPCHK(hipStreamSynchronize(e->tail_stream));
   if (e->pending.empty()) { HIPCHK(hipStreamSynchronize(s)); return TOHC_OK; }
   for (const auto &pd : e->pending)   // only the slots in use: a Counters is 2 KB now
     HIPCHK(hipMemcpyAsync(e->h_cnt.p + pd.slot, e->d_cnt.p + pd.slot, sizeof(Counters), hipMemcpyDeviceToHost, s));
@@ -773,11 +807,12 @@ static int syncEngineImpl(tohc_engine *e) {
     worst_pairs = std::max(worst_pairs, ng);
     c.aabb_tests += pd.aabb_tests; c.pair_evals += np; c.epa_evals += ne; c.gjk_evals += ng;
     c.cum_aabb_tests += pd.aabb_tests; c.cum_pair_evals += np; c.cum_epa_evals += ne; c.cum_gjk_evals += ng;
-    float ms[NEV - 1] = {0, 0, 0, 0, 0, 0};
+    float ms[NEV - 1] = {0, 0, 0, 0, 0, 0, 0, 0};
     hipEvent_t *ev = &e->events[(size_t)pd.slot * NEV];
-    for (int i = 0; i < NEV - 1; ++i) HIPCHK(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
-    c.cum_ms_fk += ms[0]; c.cum_ms_children += ms[1]; c.cum_ms_broadphase += ms[2]; c.cum_ms_gjk += ms[3]; c.cum_ms_epa += ms[4];
-    c.cum_ms_finish += ms[5];
+    for (int i = 0; i < NEV - 1; ++i)
+      if (i != 4 && i != 6) HIPCHK(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));   // 4 -> 5 and 6 -> 7 are waits between streams
+    c.cum_ms_fk += ms[0]; c.cum_ms_children += ms[1]; c.cum_ms_broadphase += ms[2]; c.cum_ms_gjk += ms[3]; c.cum_ms_epa += ms[5];
+    c.cum_ms_finish += ms[7];
     // enqueues overlap on the lanes: the device time of the call is the span from the first start to the last end
     float span = 0;
     HIPCHK(hipEventElapsedTime(&span, e->events[(size_t)e->pending.front().slot * NEV], ev[NEV - 1]));
@@ -839,6 +874,72 @@ static int64_t countAabbTests(const tohc_engine *e, const std::vector<int> &qchi
 #ifndef TOHC_FINISH_BLOCKS_PER_CU
 #define TOHC_FINISH_BLOCKS_PER_CU 4   // with TOHC_FINISH_WAVES 4 (128 VGPRs): four waves per SIMD = 4 blocks of 256 per CU (measured: 2 -> 3 blocks +5 %, 4 / 4 another +3 %)
 #endif
+// The tail of every open pass: ONE k_tail_pen and ONE k_tail_epa launch over all their penetration queues, their
+// record ranges reserved in enqueue order (k_tail_range), then each pass's k_finish on its own lane, side by side.
+static int launchTail(tohc_engine *e) {
+  if (e->open.empty()) return TOHC_OK;
+  std::vector<tohc_engine::OpenHead> heads;
+  heads.swap(e->open);   // (whatever fails below, the passes are not launched twice)
+  // a tail of one pass runs on that pass's own lane (tails of different lanes then overlap, as do their heads); a
+  // shared tail on the tail stream, after every head it serves
+  hipStream_t ts = heads.size() == 1 ? e->lane[heads[0].lane].stream : e->tail_stream;
+  TailArgs ta;
+  memset(&ta, 0, sizeof ta);
+  ta.n_heads = (int)heads.size();
+  bool work = false;
+  for (size_t i = 0; i < heads.size(); ++i) {
+    ta.h[i] = heads[i].a;
+    work |= !heads[i].empty;
+    HIPCHK(hipStreamWaitEvent(ts, e->lane[heads[i].lane].head_done, 0));
+  }
+  // the tail's time is booked on the last pass; the others get a zero-length pair of events
+  for (size_t i = 0; i + 1 < heads.size(); ++i) {
+    hipEvent_t *ev = &e->events[(size_t)heads[i].slot * NEV];
+    HIPCHK(hipEventRecord(ev[5], ts));
+    HIPCHK(hipEventRecord(ev[6], ts));
+  }
+  hipEvent_t *evl = &e->events[(size_t)heads.back().slot * NEV];
+  HIPCHK(hipEventRecord(evl[5], ts));
+  if (work) {
+    const unsigned int nh = (unsigned int)ta.n_heads;
+    const unsigned int gridN = 256 * 8;
+    if (nh == 1) {
+      const bool cast = ta.h[0].cp.cast != 0;
+      if (e->pen_group == 4) hipLaunchKernelGGL((k_tail_pen<4, 1, 2>), dim3(gridN), dim3(64), 0, ts, ta);
+      else if (cast) hipLaunchKernelGGL((k_tail_pen<1, 1, 1>), dim3(gridN), dim3(64), 0, ts, ta);
+      else hipLaunchKernelGGL((k_tail_pen<1, 1, 0>), dim3(gridN), dim3(64), 0, ts, ta);
+      if (e->group == 64) hipLaunchKernelGGL((k_tail_epa<64, 64, 1>), dim3(gridN), dim3(64), 0, ts, ta);
+      else if (e->epa_block == 16) hipLaunchKernelGGL((k_tail_epa<16, 16, 1>), dim3(gridN * 4), dim3(16), 0, ts, ta);  // one group per wavefront
+      else hipLaunchKernelGGL((k_tail_epa<16, 64, 1>), dim3(TOHC_EPA_GRID), dim3(64), 0, ts, ta);
+    } else {   // nh == TOHC_MAX_HEADS == 2
+      if (e->pen_group == 4) hipLaunchKernelGGL((k_tail_pen<4, 2, 2>), dim3(gridN * 2), dim3(64), 0, ts, ta);
+      else hipLaunchKernelGGL((k_tail_pen<1, 2, 2>), dim3(gridN * 2), dim3(64), 0, ts, ta);
+      if (e->group == 64) hipLaunchKernelGGL((k_tail_epa<64, 64, 2>), dim3(gridN * 2), dim3(64), 0, ts, ta);
+      else if (e->epa_block == 16) hipLaunchKernelGGL((k_tail_epa<16, 16, 2>), dim3(gridN * 4 * 2), dim3(16), 0, ts, ta);
+      else hipLaunchKernelGGL((k_tail_epa<16, 64, 2>), dim3(TOHC_EPA_GRID * 2), dim3(64), 0, ts, ta);
+    }
+  }
+  if (e->have_ranged) HIPCHK(hipStreamWaitEvent(ts, e->tail_ranged, 0));   // record ranges are reserved in enqueue order
+  hipLaunchKernelGGL(k_tail_range, dim3(1), dim3(1), 0, ts, ta);   // also for passes without work: they reserve an empty range
+  HIPCHK(hipEventRecord(evl[6], ts));
+  HIPCHK(hipEventRecord(e->tail_ranged, ts));
+  e->have_ranged = true;
+  for (const auto &h : heads) {
+    tohc_engine::Lane &ln = e->lane[h.lane];
+    hipEvent_t *ev = &e->events[(size_t)h.slot * NEV];
+    HIPCHK(hipStreamWaitEvent(ln.stream, e->tail_ranged, 0));
+    HIPCHK(hipEventRecord(ev[7], ln.stream));
+    if (!h.empty) {
+      if (e->group == 64) hipLaunchKernelGGL((k_finish<64>), dim3(256 * 2), dim3(256), 0, ln.stream, h.a);
+      else hipLaunchKernelGGL((k_finish<16>), dim3(256 * TOHC_FINISH_BLOCKS_PER_CU), dim3(256), 0, ln.stream, h.a);
+    }
+    HIPCHK(hipEventRecord(ev[8], ln.stream));
+    HIPCHK(hipEventRecord(ln.done, ln.stream));
+  }
+  HIPCHK(hipGetLastError());
+  return TOHC_OK;
+}
+
 static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren, const std::vector<int> &h_qchildren, CallParams cp,
                         bool robotMode, int slot, bool append) {
   const int nQ = (int)h_qchildren.size();
@@ -852,13 +953,23 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
     if (e->last_robot_mode != robotMode || e->last_want_jac != wantJ)
       return fail(e, TOHC_E_INVALID, "append: want_jacobians / query mode differ from the enqueue that started the slab");
   }
-  tohc_engine::Lane &ln = e->lane[slot % e->n_lanes];
-  tohc_engine::Lane *prev = slot > 0 ? &e->lane[(slot - 1) % e->n_lanes] : nullptr;   // the enqueue before this one, if it is still pending
+  if (!append) {   // passes of the previous slab go out before this one resets the record counter
+    const int rc = launchTail(e);
+    if (rc != TOHC_OK) return rc;
+  }
+  const int laneIdx = slot % e->n_lanes;
+  for (const auto &h : e->open)
+    if (h.lane == laneIdx) {   // the lane's queues still belong to an open pass: its tail goes out first
+      const int rc = launchTail(e);
+      if (rc != TOHC_OK) return rc;
+      break;
+    }
+  tohc_engine::Lane &ln = e->lane[laneIdx];
   hipStream_t s = ln.stream;
   hipEvent_t *ev = &e->events[(size_t)slot * NEV];
   HIPCHK(hipStreamWaitEvent(s, e->ev_fk, 0));   // pose tables of this call (FK / k_dyn_children on the main stream)
   // a new slab starts only after everything that wrote the old one
-  if (!append && prev)
+  if (!append && slot > 0)
     for (auto &other : e->lane)
       if (&other != &ln) HIPCHK(hipStreamWaitEvent(s, other.done, 0));
   HIPCHK(hipMemsetAsync(e->d_cnt.p + slot, 0, sizeof(Counters), s));
@@ -874,18 +985,20 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
   HIPCHK(e->d_records.reserve(e->max_records));
   HIPCHK(e->d_grads.reserve(e->max_records * 2 * (size_t)K));
   HIPCHK(hipEventRecord(ev[2], s));
-  if (nQ > 0 && cp.n_cast_sets > 0) {
-    DevScene sc = devScene(e);
+  tohc_engine::OpenHead oh;
+  oh.slot = slot; oh.lane = laneIdx; oh.empty = !(nQ > 0 && cp.n_cast_sets > 0);
+  const bool sep1 = cp.gap == 0 && cp.cast;  // poses mode keeps the end-of-sweep poses in their own tables
+  NarrowArgs &a = oh.a;
+  memset(&a, 0, sizeof a);
+  a.sc = devScene(e); a.dm = dm; a.rb = devRobot(e); a.cp = cp;
+  a.dynXf0 = e->d_dynXf.p; a.dynXf1 = sep1 ? e->d_dynXf1.p : e->d_dynXf.p;
+  a.linkQT = robotMode ? e->d_linkQT.p : nullptr;
+  a.dofs = robotMode ? e->d_dofs.p : nullptr;
+  a.pairs = ln.pairs.p; a.epaq = ln.epaq.p; a.penq = ln.penq.p; a.hits = ln.hits.p; a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p; a.rec_base = e->d_rec_base.p + slot;
+  a.records = e->d_records.p; a.grads = e->d_grads.p; a.dbg = e->d_dbg.p;
+  if (!oh.empty) {
     const size_t blocks = (size_t)cp.n_cast_sets * nQ;
     if (blocks > 0x7fffffffull) return fail(e, TOHC_E_CAPACITY, "broadphase grid too large (%zu blocks)", blocks);
-    const bool sep1 = cp.gap == 0 && cp.cast;  // poses mode keeps the end-of-sweep poses in their own tables
-    NarrowArgs a;
-    a.sc = sc; a.dm = dm; a.rb = devRobot(e); a.cp = cp;
-    a.dynXf0 = e->d_dynXf.p; a.dynXf1 = sep1 ? e->d_dynXf1.p : e->d_dynXf.p;
-    a.linkQT = robotMode ? e->d_linkQT.p : nullptr;
-    a.dofs = robotMode ? e->d_dofs.p : nullptr;
-    a.pairs = ln.pairs.p; a.epaq = ln.epaq.p; a.penq = ln.penq.p; a.hits = ln.hits.p; a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p; a.rec_base = e->d_rec_base.p + slot;
-    a.records = e->d_records.p; a.grads = e->d_grads.p; a.dbg = e->d_dbg.p;
     CullArgs ca;
     ca.a = a; ca.qchildren = d_qchildren; ca.nQ = nQ;
     ca.dynAabb0 = e->d_dynAabb.p; ca.dynAabb1 = sep1 ? e->d_dynAabb1.p : e->d_dynAabb.p;
@@ -905,33 +1018,13 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
       if (cp.cast) hipLaunchKernelGGL((k_gjk<16, true, 256>), dim3(gridN), dim3(256), 0, s, a);
       else hipLaunchKernelGGL((k_gjk<16, false, 256>), dim3(gridN), dim3(256), 0, s, a);
     }
-    HIPCHK(hipEventRecord(ev[4], s));
-    if (e->pen_group == 4) {
-      if (cp.cast) hipLaunchKernelGGL((k_pen<true, 4>), dim3(gridN), dim3(64), 0, s, a);
-      else hipLaunchKernelGGL((k_pen<false, 4>), dim3(gridN), dim3(64), 0, s, a);
-    } else {
-      if (cp.cast) hipLaunchKernelGGL((k_pen<true, 1>), dim3(gridN), dim3(64), 0, s, a);
-      else hipLaunchKernelGGL((k_pen<false, 1>), dim3(gridN), dim3(64), 0, s, a);
-    }
-    if (e->group == 64) hipLaunchKernelGGL((k_epa<64, 64>), dim3(gridN), dim3(64), 0, s, a);
-    else if (e->epa_block == 16) hipLaunchKernelGGL((k_epa<16, 16>), dim3(gridN * 4), dim3(16), 0, s, a);  // one group per wavefront
-    else hipLaunchKernelGGL((k_epa<16, 64>), dim3(TOHC_EPA_GRID), dim3(64), 0, s, a);
-    HIPCHK(hipEventRecord(ev[5], s));
-    // k_finish appends to the shared slab: its range starts where the previous enqueue's ends, known as soon as that
-    // one's k_epa is through (k_range) -- the two k_finish kernels themselves run side by side
-    if (append && prev && prev != &ln) HIPCHK(hipStreamWaitEvent(s, prev->ranged, 0));
-    hipLaunchKernelGGL(k_range, dim3(1), dim3(1), 0, s, e->d_cnt.p + slot, cp.seg_cap, e->d_nrec.p, e->d_rec_base.p + slot);
-    HIPCHK(hipEventRecord(ln.ranged, s));
-    if (e->group == 64) hipLaunchKernelGGL((k_finish<64>), dim3(256 * 2), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_finish<16>), dim3(256 * TOHC_FINISH_BLOCKS_PER_CU), dim3(256), 0, s, a);
-    HIPCHK(hipEventRecord(ev[6], s));
     HIPCHK(hipGetLastError());
   } else {
-    for (int i = 3; i < NEV; ++i) HIPCHK(hipEventRecord(ev[i], s));
-    if (append && prev && prev != &ln) HIPCHK(hipStreamWaitEvent(s, prev->ranged, 0));   // keeps the chain of ranges in enqueue order
-    HIPCHK(hipEventRecord(ln.ranged, s));
+    HIPCHK(hipEventRecord(ev[3], s));
   }
-  HIPCHK(hipEventRecord(ln.done, s));
+  HIPCHK(hipEventRecord(ev[4], s));
+  HIPCHK(hipEventRecord(ln.head_done, s));
+  e->open.push_back(oh);
   tohc_engine::Pending pd;
   pd.slot = slot;
   pd.aabb_tests = countAabbTests(e, h_qchildren, cp);
@@ -940,6 +1033,7 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
   if (!append || noSlab) { e->last_robot_mode = robotMode; e->last_want_jac = wantJ; }
   if (!append) e->slab_state = 0;   // a new slab is being filled
   e->last_T = cp.T;
+  if ((int)e->open.size() >= e->max_open) return launchTail(e);
   return TOHC_OK;
 }
 
@@ -947,6 +1041,10 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
 static int launchSweep(tohc_engine *e, const DynMap &dm, const int *d_qchildren, const std::vector<int> &h_qchildren, CallParams cp, bool robotMode,
                        int slot) {
   const int nQ = (int)h_qchildren.size();
+  {
+    const int rc = launchTail(e);   // always a new slab: what is open belongs to the old one
+    if (rc != TOHC_OK) return rc;
+  }
   tohc_engine::Lane &ln = e->lane[slot % e->n_lanes];
   hipStream_t s = ln.stream;
   hipEvent_t *ev = &e->events[(size_t)slot * NEV];
@@ -1014,7 +1112,12 @@ int tohc_stage_dofs(tohc_engine *e, const double *dofs, int B, int T) {
   if (!dofs || B < 1 || T < 1) return fail(e, TOHC_E_INVALID, "dofs is null or B/T < 1");
   HIPCHK(hipSetDevice(e->device));
   const size_t n_sets = (size_t)B * T;
+  {
+    const int rc = launchTail(e);
+    if (rc != TOHC_OK) return rc;
+  }
   for (auto &ln : e->lane) HIPCHK(hipStreamSynchronize(ln.stream));   // enqueues still reading the old tables
+  HIPCHK(hipStreamSynchronize(e->tail_stream));
   e->fk_done = false;
   HIPCHK(upload(e->d_dofs, dofs, n_sets * e->K, e->stream));
   HIPCHK(e->d_linkQT.reserve(n_sets * e->n_links * 7));
@@ -1040,6 +1143,8 @@ static int enqueueRobot(tohc_engine *e, int gap, int cast, int filter_mask, int 
   DynMap dm = dynMapRobot(e);
   // FK once per linearization: every enqueue that starts a new slab runs it; appended passes reuse its tables
   if (!append || !e->fk_done) {
+    rc = launchTail(e);   // (their k_finish kernels read the pose tables too)
+    if (rc != TOHC_OK) return rc;
     hipStream_t s = e->stream;
     for (auto &ln : e->lane) HIPCHK(hipStreamWaitEvent(s, ln.done, 0));   // pending enqueues still read the tables
     HIPCHK(hipEventRecord(ev[0], s));

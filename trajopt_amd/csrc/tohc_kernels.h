@@ -9,9 +9,10 @@
 //                   NSHARD counters (a single word saturates at ~88 atomics/us, MI355X_MICROARCH.md "dequeue")
 //   k_gjk           one group of G lanes per pair: GJK closest points (tohc_narrow.h); separated pairs that pass the
 //                   contact filter go to the hit list, penetrating / degenerate ones to the EPA queue
-//   k_pen           the queued pairs, one lane per pair: GJK2 of the penetration solver; origin outside -> Distance
-//                   fall-back, done; origin inside -> on to k_epa with the GJK2 state
-//   k_epa           EPA proper, one group of 16 lanes per pair, face / vertex pools in LDS -> hit list
+//   k_tail_pen      the queued pairs of EVERY open pass (TailArgs), one lane per pair: GJK2 of the penetration solver;
+//                   origin outside -> Distance fall-back, done; origin inside -> on to k_tail_epa with the GJK2 state
+//   k_tail_epa      EPA proper, one group of 16 lanes per pair, face / vertex pools in LDS -> hit list
+//   k_tail_range    reserves each open pass's record range in the shared slab, in enqueue order
 //   k_finish        one group per hit: cast classification, record write, fused Jacobian rows (fp64); the p-th hit
 //                   becomes record base+p, so no atomics here
 // All queues are sharded NSHARD ways by producer block; consumers walk them through a 16-entry prefix.
@@ -918,19 +919,39 @@ __device__ __forceinline__ void loadQueued(const NarrowArgs &a, const EpaRec &e,
   st.iters = 0;
 }
 
-// k_pen: first stage of calcPenDepth for the pairs k_gjk queued, a group of G lanes per pair (G = 4: the two hulls sit in
+// -----------------------------------------------------------------------------------------------------------------
+// The penetration tail.  Only ~10 % of the pairs k_gjk iterates on need calcPenDepth, and one pass (discrete or cast) of
+// one linearization does not hold enough of them to fill the chip: launched per pass, k_pen kept 0.55 waves per SIMD
+// resident and k_epa 1.2.  So the passes that are open when the tail is launched (engine: launchTail) share ONE launch
+// of each tail kernel: TailArgs carries the NarrowArgs of every open pass ("head"), a block works for head
+// blockIdx % n_heads (wave-uniform, so the head's arguments stay scalar); k_tail_epa's blocks, when their own head's
+// queue is used up, take pairs from the other heads' queues.
+// -----------------------------------------------------------------------------------------------------------------
+#define TOHC_MAX_HEADS 2
+struct TailArgs {
+  int n_heads;
+  NarrowArgs h[TOHC_MAX_HEADS];
+};
+
+// k_tail_pen: first stage of calcPenDepth for the pairs k_gjk queued, a group of G lanes per pair (G = 4: the two hulls sit in
 // the group's registers, 16 vertices a lane, so a support query is 16 dot products and two DPP steps instead of a
 // scan through L2; G = 1: one lane per pair, hulls read from memory).  GJK2 needs only four support vertices, so its
 // whole state fits a 140-byte LDS record per group.  Pairs whose origin lies inside the Minkowski difference go on to
-// k_epa with that state (PenRec); for the rest the Distance fall-back runs here and the pair is finished.
+// k_tail_epa with that state (PenRec); for the rest the Distance fall-back runs here and the pair is finished.
 #ifndef TOHC_PEN_WAVES
 #define TOHC_PEN_WAVES 2
 #endif
-template <bool CAST, int G>
-__global__ void __launch_bounds__(64, TOHC_PEN_WAVES) k_pen(NarrowArgs a) {
+// NH: heads in this launch (1: a constant index, the arguments stay where the launch put them); CAST: 0 / 1 = every
+// pair of the launch is discrete / cast (known at compile time when there is one head), 2 = ask the head
+template <int G, int NH, int CAST>
+__global__ void __launch_bounds__(64, TOHC_PEN_WAVES) k_tail_pen(TailArgs ta) {
   __shared__ G2Mem mem[64 / G];
-  const unsigned int gid = (blockIdx.x * 64 + threadIdx.x) / G;
-  const unsigned int nlanes = gridDim.x * 64 / G;
+  const int head = NH == 1 ? 0 : (int)(blockIdx.x % (unsigned int)NH);
+  const NarrowArgs &a = ta.h[head];
+  const unsigned int bid = blockIdx.x / (unsigned int)NH, nblocks = gridDim.x / (unsigned int)NH;
+  const unsigned int gid = (bid * 64 + threadIdx.x) / G;
+  const unsigned int nlanes = nblocks * 64 / G;
+  const bool cast = CAST == 2 ? a.cp.cast != 0 : CAST == 1;
   QPrefix pre;
   qprefix(&a.cnt->sh[0].n_epa, a.cp.seg_cap, pre);
   const unsigned int nepa = pre.start[TOHC_NSHARD];
@@ -943,7 +964,7 @@ __global__ void __launch_bounds__(64, TOHC_PEN_WAVES) k_pen(NarrowArgs a) {
     Cvx<G> A, B;
     Xf tA, tB, lA, lB;
     GjkState st;
-    loadQueued<G>(a, e, CAST, A, B, tA, tB, st);
+    loadQueued<G>(a, e, cast, A, B, tA, tB, st);
     penLocal(tA, tB, st.offset, lA, lB);
     V3 tmpA = mk(0, 0, 0), tmpB = mk(0, 0, 0), sep = mk(0, 0, 0);
     bool isValid2 = false;
@@ -964,7 +985,7 @@ __global__ void __launch_bounds__(64, TOHC_PEN_WAVES) k_pen(NarrowArgs a) {
         a.cnt->overflow = 1;
       }
     }
-    if (toEpa) st.isValid = false;   // no contact yet: k_epa decides
+    if (toEpa) st.isValid = false;   // no contact yet: k_tail_epa decides
     else gjkFinishTail(isValid2, sep, tmpA, tmpB, st);
     pushIfContact<G>(a, (unsigned int)e.pair, st, md2);
     if (Grp<G>::lane() == 0) sups += g.nsup;
@@ -972,59 +993,65 @@ __global__ void __launch_bounds__(64, TOHC_PEN_WAVES) k_pen(NarrowArgs a) {
   waveAdd(&a.cnt->sh[blockIdx.x % TOHC_NSHARD].n_pen_sups, sups);
 }
 
-// k_epa: second stage (EPA proper) for the pairs k_pen handed over, one group of G lanes per pair, pools in LDS
-template <int G, int BLOCK>
-__global__ void __launch_bounds__(BLOCK, TOHC_EPA_WAVES) k_epa(NarrowArgs a) {
+// k_tail_epa: second stage (EPA proper) for the pairs k_tail_pen handed over, one group of G lanes per pair, pools in LDS
+template <int G, int BLOCK, int NH>
+__global__ void __launch_bounds__(BLOCK, TOHC_EPA_WAVES) k_tail_epa(TailArgs ta) {
   __shared__ EpaMem mem[BLOCK / G];
   const int groupsPerBlock = BLOCK / G;
-  const unsigned int cap2 = a.cp.seg_cap / TOHC_PEN_DIV;
-  QPrefix pre;
-  qprefix(&a.cnt->sh[0].n_pen, cap2, pre);
-  const unsigned int npen = pre.start[TOHC_NSHARD];
   EpaMem *m = &mem[threadIdx.x / G];
-  float md2 = a.cp.breaking;
-  md2 *= md2;
-  // Pairs are handed out on demand, BLOCK / G at a time per wavefront (a block is one wavefront or less): EPA runs take
-  // from 2 to 255 iterations, and with a fixed share per group the kernel lasted as long as its unluckiest group.
   unsigned int sups = 0;
-  for (;;) {
-    unsigned int first = 0;
-    if (threadIdx.x == 0) first = atomicAdd(&a.cnt->epa_next, (unsigned int)groupsPerBlock);
-    first = __shfl(first, 0);
-    if (first >= npen) break;
-    const unsigned int i = first + threadIdx.x / G;
-    if (i >= npen) continue;
-    const PenRec *r = &a.penq[qlocate(pre, cap2, i)];
-    const EpaRec e = r->e;
-    Cvx<G> A, B;
-    Xf tA, tB, lA, lB;
-    GjkState st;
-    loadQueued<G>(a, e, a.cp.cast != 0, A, B, tA, tB, st);
-    penLocal(tA, tB, st.offset, lA, lB);
-    Gjk2<G, EpaMem> g;
-    penRestore<G>(m, r->h, A, B, lA, lB, g);
-    V3 tmpA = mk(0, 0, 0), tmpB = mk(0, 0, 0), sep = mk(0, 0, 0);
-    bool isValid2 = false;
+  for (int hh = 0; hh < NH; ++hh) {   // the block's own head first, then whatever the others still hold
+    const int head = NH == 1 ? 0 : (int)((blockIdx.x + (unsigned int)hh) % (unsigned int)NH);
+    const NarrowArgs &a = ta.h[head];
+    const unsigned int cap2 = a.cp.seg_cap / TOHC_PEN_DIV;
+    QPrefix pre;
+    qprefix(&a.cnt->sh[0].n_pen, cap2, pre);
+    const unsigned int npen = pre.start[TOHC_NSHARD];
+    float md2 = a.cp.breaking;
+    md2 *= md2;
+    // Pairs are handed out on demand, BLOCK / G at a time per wavefront (a block is one wavefront or less): EPA runs take
+    // from 2 to 255 iterations, and with a fixed share per group the kernel lasted as long as its unluckiest group.
+    for (;;) {
+      unsigned int first = 0;
+      if (threadIdx.x == 0) first = atomicAdd(&a.cnt->epa_next, (unsigned int)groupsPerBlock);
+      first = __shfl(first, 0);
+      if (first >= npen) break;
+      const unsigned int i = first + threadIdx.x / G;
+      if (i >= npen) continue;
+      const PenRec *r = &a.penq[qlocate(pre, cap2, i)];
+      const EpaRec e = r->e;
+      Cvx<G> A, B;
+      Xf tA, tB, lA, lB;
+      GjkState st;
+      loadQueued<G>(a, e, a.cp.cast != 0, A, B, tA, tB, st);
+      penLocal(tA, tB, st.offset, lA, lB);
+      Gjk2<G, EpaMem> g;
+      penRestore<G>(m, r->h, A, B, lA, lB, g);
+      V3 tmpA = mk(0, 0, 0), tmpB = mk(0, 0, 0), sep = mk(0, 0, 0);
+      bool isValid2 = false;
 #if defined(TOHC_EPA_PROF)
-    const unsigned long long tw0 = wall_clock64(), tc0 = clock64();
-    EpaProf prof;
-    penStage2<G>(m, lA, lB, g, isValid2, sep, tmpA, tmpB, &prof);
-    if (Grp<G>::lane() == 0 && a.dbg) {
-      atomicAdd(&a.dbg[0], 1ull);
-      atomicAdd(&a.dbg[1], wall_clock64() - tw0);
-      atomicAdd(&a.dbg[2], clock64() - tc0);
-      atomicMax(&a.dbg[3], wall_clock64() - tw0);
-      for (int k = 0; k < 8; ++k) { atomicAdd(&a.dbg[8 + k], prof.t[k]); atomicAdd(&a.dbg[16 + k], (unsigned long long)prof.n[k]); }
-    }
+      const unsigned long long tw0 = wall_clock64(), tc0 = clock64();
+      EpaProf prof;
+      penStage2<G>(m, lA, lB, g, isValid2, sep, tmpA, tmpB, &prof);
+      if (Grp<G>::lane() == 0 && a.dbg) {
+        atomicAdd(&a.dbg[0], 1ull);
+        atomicAdd(&a.dbg[1], wall_clock64() - tw0);
+        atomicAdd(&a.dbg[2], clock64() - tc0);
+        atomicMax(&a.dbg[3], wall_clock64() - tw0);
+        for (int k = 0; k < 8; ++k) { atomicAdd(&a.dbg[8 + k], prof.t[k]); atomicAdd(&a.dbg[16 + k], (unsigned long long)prof.n[k]); }
+      }
 #else
-    penStage2<G>(m, lA, lB, g, isValid2, sep, tmpA, tmpB);
+      penStage2<G>(m, lA, lB, g, isValid2, sep, tmpA, tmpB);
 #endif
-    gjkFinishTail(isValid2, sep, tmpA, tmpB, st);
-    pushIfContact<G>(a, (unsigned int)e.pair, st, md2);
-    if (Grp<G>::lane() == 0) sups += g.nsup;
+      gjkFinishTail(isValid2, sep, tmpA, tmpB, st);
+      pushIfContact<G>(a, (unsigned int)e.pair, st, md2);
+      if (Grp<G>::lane() == 0) sups += g.nsup;
+    }
   }
-  if (BLOCK >= 64) waveAdd(&a.cnt->sh[blockIdx.x % TOHC_NSHARD].n_epa_sups, sups);
-  else if (sups) atomicAdd(&a.cnt->sh[blockIdx.x % TOHC_NSHARD].n_epa_sups, sups);
+  // (work counter only: booked on the block's own head)
+  unsigned int *ctr = &ta.h[NH == 1 ? 0 : blockIdx.x % (unsigned int)NH].cnt->sh[blockIdx.x % TOHC_NSHARD].n_epa_sups;
+  if (BLOCK >= 64) waveAdd(ctr, sups);
+  else if (sups) atomicAdd(ctr, sups);
 }
 
 // point Jacobian of `link` at world point p, column k: CalculateActiveJacobian as used by PositionJacobian
@@ -1234,13 +1261,17 @@ __global__ void __launch_bounds__(256, TOHC_FINISH_WAVES) k_finish(NarrowArgs a)
   }
 }
 
-// between k_epa and k_finish: the hit count of this enqueue is final, so its record range is too.  Enqueues reserve
-// their ranges in enqueue order (an event chain between the lanes); their k_finish kernels then run independently.
-__global__ void k_range(Counters *cnt, unsigned int segCap, unsigned int *n_records, unsigned int *rec_base) {
-  QPrefix pre;
-  qprefix(&cnt->sh[0].n_hits, segCap, pre);
-  *rec_base = *n_records;
-  *n_records += pre.start[TOHC_NSHARD];
+// between k_tail_epa and the k_finish launches: the hit counts of the open passes are final, so their record ranges are
+// too.  Ranges are reserved in enqueue order (the heads are in that order; tails run one after another on one stream);
+// the passes' k_finish kernels then run independently, side by side.
+__global__ void k_tail_range(TailArgs ta) {
+  for (int h = 0; h < ta.n_heads; ++h) {
+    const NarrowArgs &a = ta.h[h];
+    QPrefix pre;
+    qprefix(&a.cnt->sh[0].n_hits, a.cp.seg_cap, pre);
+    *const_cast<unsigned int *>(a.rec_base) = *a.n_records;
+    *a.n_records += pre.start[TOHC_NSHARD];
+  }
 }
 
 }  // namespace tohc
