@@ -36,7 +36,7 @@ enum {
   TOHC_E_UNSUPPORTED = -5
 };
 
-enum { TOHC_BOX = 0, TOHC_HULL = 1, TOHC_SPHERE = 2 /* rejected: TOHC_E_UNSUPPORTED */, TOHC_CYLZ = 3 };                 /* createShapePrimitive, bullet_collision_checker.cpp:134-212 */
+enum { TOHC_BOX = 0, TOHC_HULL = 1, TOHC_SPHERE = 2, TOHC_CYLZ = 3 };  /* createShapePrimitive, bullet_collision_checker.cpp:134-212; param[0]: box hx / sphere radius / cylinder radius */
 enum { TOHC_GROUP_ROBOT = 1, TOHC_GROUP_KINBODY = 2 };  /* CollisionFilterGroups, collision_checker.hpp:32-35        */
 enum { TOHC_CC_NONE = 0, TOHC_CC_TIME0 = 1, TOHC_CC_TIME1 = 2, TOHC_CC_BETWEEN = 3 }; /* CastCollisionType, :12-17  */
 enum { TOHC_J_FIXED = 0, TOHC_J_REVOLUTE = 1, TOHC_J_PRISMATIC = 2 };

@@ -1289,7 +1289,22 @@ static int pairEval(world_t *w, const cvx_t *A, const xf *tA, const cvx_t *B, co
   md *= md;
   gjkout_t o;
   w->pair_evals++;
-  gjkPair(A, B, tA, tB, md, &o);
+  if (!A->cast && !B->cast && A->s->kind == ORA_SPHERE && B->s->kind == ORA_SPHERE) {
+    /* two plain spheres never reach GJK: the dispatch matrix holds btSphereSphereCollisionAlgorithm for them
+     * (btDefaultCollisionConfiguration.cpp:219-222; also for a compound's sphere child, whose algorithm is found by
+     * the CHILD's shape type, btCompoundCollisionAlgorithm.cpp:65).  processCollision
+     * [btSphereSphereCollisionAlgorithm.cpp:42-89]: no contact at all while the surfaces are apart. */
+    v3 diff = vsub(tA->o, tB->o);
+    float len = vlen(diff);
+    float radius0 = A->s->dims.x * 1.0f, radius1 = B->s->dims.x * 1.0f; /* getRadius(): implicit dims.x * scaling.x */
+    if (len > (radius0 + radius1)) return 0;
+    o.distance = len - (radius0 + radius1);
+    o.normalOnB = V(1, 0, 0);
+    if (len > SIMD_EPSILON) o.normalOnB = vdiv(diff, len);
+    o.pointOnB = vadd(tB->o, vscale(o.normalOnB, radius1));
+    o.valid = 1;
+  } else
+    gjkPair(A, B, tA, tB, md, &o);
   if (!o.valid) return 0;
   /* btBridgedManifoldResult::addContactPoint [cw:1068-1086]; CollisionCollector [bcc:398-408] */
   if ((double)o.distance > (double)w->d) return 0;
@@ -1410,6 +1425,22 @@ int ora_cast_vs_all(void *h, const double *objT7, const int *q, int nq, const do
           aabb_t bx = shapeAabb(cx.s, &tx, w->d);
           w->aabb_tests++;
           if (!aabbOverlap(bq, bx)) continue;
+          if (w->obj_compound[X] && cq.s->kind == ORA_SPHERE && cx.s->kind == ORA_SPHERE) {
+            /* The one pair kind whose reference cull is NOT grown by d on either side: the compound's child test
+             * [cpa:128-132] takes btSphereShape::getAabb (centre +- radius, untouched by the SHAPE_EXPANSION patch) for
+             * the child and CastHullShape::getAabb [bcc:850-856] = the union of the same at both ends of the sweep for
+             * the swept sphere.  A swept sphere passing a compound's sphere child at a distance in (0, d] is therefore
+             * culled by the reference (every other kind has at least one box grown by d: nothing within d is lost). */
+            float rq = cq.s->margin, rx = cx.s->margin;
+            v3 lo0 = vsub(tf0.o, V(rq, rq, rq)), hi0 = vadd(tf0.o, V(rq, rq, rq));
+            v3 lo1 = vsub(tw1.o, V(rq, rq, rq)), hi1 = vadd(tw1.o, V(rq, rq, rq));
+            aabb_t bs = {V(fminf(lo0.x, lo1.x), fminf(lo0.y, lo1.y), fminf(lo0.z, lo1.z)), V(fmaxf(hi0.x, hi1.x), fmaxf(hi0.y, hi1.y), fmaxf(hi0.z, hi1.z))};
+            aabb_t bc = {vsub(tx.o, V(rx, rx, rx)), vadd(tx.o, V(rx, rx, rx))};
+            if (!aabbOverlap(bs, bc)) {
+              w->pair_evals++; /* it survived the engine's own cull: a pair evaluation, which ends here */
+              continue;
+            }
+          }
           ora_contact c;
           memset(&c, 0, sizeof c);
           int kept, castFirst;

@@ -38,10 +38,20 @@ long g_iter_hist[64];
 long g_epa_hist[2];
 long g_pre[8];
 bool pairEval(World *w, const Cvx<1> &A, const Xf &tA, const Cvx<1> &B, const Xf &tB, ora_contact *c) {
-  float md = w->breaking;
-  md *= md;
+  const float md = pairMaxDist2<1>(A, B, w->breaking);
   GjkState st;
   w->pair_evals++;
+  if (isSphereSphere<1>(A, B)) {   // as k_gjk does
+    PairOut o;
+    sphereSphere(tA.o, A.margin, tB.o, B.margin, o);
+    if (!o.valid || (double)o.distance > (double)w->d) return false;
+    V3 pA = o.pointOnB + o.normalOnB * o.distance;
+    c->dist = o.distance;
+    c->n[0] = o.normalOnB.x; c->n[1] = o.normalOnB.y; c->n[2] = o.normalOnB.z;
+    c->ptA[0] = pA.x; c->ptA[1] = pA.y; c->ptA[2] = pA.z;
+    c->ptB[0] = o.pointOnB.x; c->ptB[1] = o.pointOnB.y; c->ptB[2] = o.pointOnB.z;
+    return true;
+  }
   int pre = 0;
   {
     float lim = w->d * 1.01f + 1e-4f;
@@ -100,6 +110,9 @@ void *emu_create(const ora_scene *sc) {
     if (s.kind == ORA_BOX) {
       float m = safeMargin(0.04f, p[0], p[1], p[2]);
       s.dims = mk(((p[0] * 1.0f - m) + m) - 0.0f, ((p[1] * 1.0f - m) + m) - 0.0f, ((p[2] * 1.0f - m) + m) - 0.0f);
+      s.lmin = -s.dims; s.lmax = s.dims;
+    } else if (s.kind == ORA_SPHERE) {
+      s.dims = mk(p[0], p[0], p[0]);
       s.lmin = -s.dims; s.lmax = s.dims;
     } else if (s.kind == ORA_CYLZ) {
       float m = safeMargin(0.04f, p[0], p[0], p[1]);
@@ -196,6 +209,10 @@ int emu_cast_vs_all(void *h, const double *objT7, const int *q, int nq, const do
           ora_contact c;
           memset(&c, 0, sizeof c);
           bool kept, castFirst;
+          if (w->compound[X] && cq.kind == KIND_SPHERE && cx.kind == KIND_SPHERE && castSphereChildCulled(tf0.o, xfApply(tf0, cq.t01.o), cq.margin, tx.o, cx.margin)) {
+            w->pair_evals++;   // as k_gjk does: the evaluation ends at the reference's child-box test
+            continue;
+          }
           if (w->compound[X]) { kept = pairEval(w, cx, tx, cq, tf0, &c); c.objA = X; c.childA = xc; c.objB = Q; c.childB = qc; castFirst = false; }
           else { kept = pairEval(w, cq, tf0, cx, tx, &c); c.objA = Q; c.childA = qc; c.objB = X; c.childB = xc; castFirst = true; }
           if (!kept) continue;

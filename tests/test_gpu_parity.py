@@ -82,12 +82,18 @@ def test_golden_fixtures_bit_exact(eng, path):
         util.assert_same_contacts(util.records_to_contacts(rec), z["cast_%d" % i], "cast d=%g" % d)
 
 
-@pytest.mark.parametrize("seed,spread", [(200, 0.6), (201, 0.3), (202, 0.25), (203, 0.45), (204, 0.3), (205, 1.0), (320, 0.3), (321, 0.5), (322, 0.25)])
+@pytest.mark.parametrize("seed,spread", [(200, 0.6), (201, 0.3), (202, 0.25), (203, 0.45), (204, 0.3), (205, 1.0), (320, 0.3), (321, 0.5), (322, 0.25),
+                                         (940, 0.35), (941, 0.3), (942, 0.5), (943, 0.25)])
 def test_random_scenes_vs_oracle_poses_api(eng, seed, spread):
     """Several pose sets per call (the batch axis), discrete and cast, dense (EPA heavy) and sparse.
-    Seeds >= 300: half of the shapes are z-cylinders (GT_Cylinder, bullet_collision_checker.cpp:153-158)."""
+    Seeds >= 300: half of the shapes are z-cylinders (GT_Cylinder, bullet_collision_checker.cpp:153-158).
+    Seeds >= 900: ~45 % spheres (GT_Sphere, :150-152) -- GJK / EPA with the radius as margin, the analytic sphere-sphere
+    algorithm, swept spheres, the unexpanded child-box cull of a swept sphere against a compound's sphere child."""
     rng = np.random.default_rng(seed)
-    s, objT, robot = synth.random_scene(rng, spread=spread, n_static=8, n_robot=5, round_prob=0.5 if seed >= 300 else 0.0)
+    if seed >= 900:
+        s, objT, robot = synth.random_scene(rng, spread=spread, n_static=8, n_robot=6, round_prob=0.9, spheres=True)
+    else:
+        s, objT, robot = synth.random_scene(rng, spread=spread, n_static=8, n_robot=5, round_prob=0.5 if seed >= 300 else 0.0)
     nsets = 4
     sets = np.stack([objT] + [np.array([synth.random_T7(rng, -spread, spread) for _ in range(len(objT))]) for _ in range(nsets - 1)])
     T1 = sets[:, robot].copy()
@@ -100,11 +106,18 @@ def test_random_scenes_vs_oracle_poses_api(eng, seed, spread):
         eng.set_contact_distance(d)
         w.set_contact_distance(d)
         rec = eng.links_vs_all_poses(sets, robot)
+        pe_d = eng.counters()["pair_evals"]
         recc = eng.cast_vs_all_poses(sets, robot, T1)
+        pe_c = eng.counters()["pair_evals"]
+        c0 = w.counter(0)
         for k in range(nsets):
             util.assert_same_contacts(util.records_to_contacts(rec[rec["problem"] == k]), w.links_vs_all(sets[k], robot), "disc set %d" % k)
+        c1 = w.counter(0)
+        for k in range(nsets):
             util.assert_same_contacts(util.records_to_contacts(recc[recc["problem"] == k]),
                                       w.cast_vs_all(sets[k], robot, sets[k][robot], T1[k]), "cast set %d" % k)
+        # the unit of the headline metric: both sides count the same pair evaluations (box-cull survivors)
+        assert (pe_d, pe_c) == (c1 - c0, w.counter(0) - c1)
     w.close()
 
 
@@ -156,12 +169,12 @@ def test_reference_continuous_check_known_answer(eng):
     assert len(eng.continuous_check_trajectory(np.array([[-1.9, 0.0], [-1.9, 1.9], [1.9, 3.8]]), 1, 3)) == 0
 
 
-@pytest.mark.parametrize("seed,spread", [(500, 0.8), (501, 1.5), (502, 0.4), (503, 1.5), (504, 0.8), (505, 0.6)])
+@pytest.mark.parametrize("seed,spread", [(500, 0.8), (501, 1.5), (502, 0.4), (503, 1.5), (504, 0.8), (505, 0.6), (950, 0.6), (951, 0.8)])
 def test_continuous_check_random_scenes_vs_oracle(eng, seed, spread):
-    """ContinuousCheckTrajectory on explicit poses (boxes, hulls, cylinders, compounds) against the CPU oracle, which is
-    bit-exact against the reference's convexSweepTest (tests/test_oracle_cpu.py)."""
+    """ContinuousCheckTrajectory on explicit poses (boxes, hulls, cylinders, compounds; seeds >= 900: spheres) against the
+    CPU oracle, which is bit-exact against the reference's convexSweepTest (tests/test_oracle_cpu.py)."""
     rng = np.random.default_rng(seed)
-    s, objT, robot = synth.random_scene(rng, spread=spread, n_static=8, n_robot=5, round_prob=0.3 if seed % 2 else 0.0)
+    s, objT, robot = synth.random_scene(rng, spread=spread, n_static=8, n_robot=5, round_prob=0.8 if seed >= 900 else (0.3 if seed % 2 else 0.0), spheres=seed >= 900)
     nst = 5
     traj = np.stack([np.array([synth.random_T7(rng, -spread, spread) for _ in robot]) for _ in range(nst)])
     sets = np.tile(objT[None], (nst, 1, 1))
@@ -240,6 +253,41 @@ def test_robot_linearization_vs_oracle(eng, active, B_, T_):
     w.close()
 
 
+def test_robot_vs_spheres_and_cylinders(eng):
+    """The robot path (FK, broadphase pre-test with margins, GJK / EPA, Jacobian epilogue) with sphere and cylinder
+    obstacles (GT_Sphere / GT_Cylinder, bullet_collision_checker.cpp:150-158), bare and as children of a compound,
+    and a sphere attached to a robot link's compound -- discrete (sphere-sphere analytic included) and cast."""
+    s = M.Scene()
+    rb = synth.pr2_like(s, seed=0, active="rightarm")
+    rng = np.random.default_rng(21)
+    ids, Ts = [], []
+    for i in range(10):
+        ids.append(s.add_object([(s.add_sphere(rng.uniform(0.04, 0.15)), M.IDENT7)], M.GROUP_KINBODY, name="ball%d" % i))
+        Ts.append(synth.T7(rng.uniform([0.3, -0.8, 0.3], [1.0, 0.3, 1.3])))
+    ids.append(s.add_object([(s.add_sphere(0.08), synth.T7((0.1, 0, 0))), (s.add_cylinder(0.05, 0.2), synth.T7((-0.1, 0, 0), (1, 0, 0), 0.7)),
+                             (s.add_sphere(0.05), synth.T7((0, 0.12, 0)))], M.GROUP_KINBODY, compound=True, name="cluster"))
+    Ts.append(synth.T7((0.7, -0.3, 0.9)))
+    s.finalize(); rb.finalize()
+    static_T = synth.static_poses(s, ids, np.array(Ts))
+    B_, T_ = 3, 8
+    dofs = np.stack([synth.straight_line(rb.q_robot[1:8] + rng.uniform(-0.5, 0.5, 7), rb.q_robot[1:8] + rng.uniform(-1.0, 1.0, 7), T_) for _ in range(B_)])
+    eng.upload_scene(s, static_T)
+    eng.upload_robot(rb)
+    eng.set_contact_distance(0.09)
+    w = B.oracle_world(s)
+    w.set_contact_distance(0.09)
+    n = 0
+    for cast in (False, True):
+        rec, g = eng.cast_vs_all_batch(dofs, B_, T_, 1) if cast else eng.links_vs_all_batch(dofs, B_, T_)
+        for b in range(B_):
+            orec, og = w.linearize(rb, static_T, dofs[b], cast=cast)
+            sel = rec["problem"] == b
+            util.assert_same_linearization(rec[sel], g[sel], orec, og, "spheres cast=%s b=%d" % (cast, b))
+            n += len(orec)
+    assert n > 50
+    w.close()
+
+
 def test_allowed_matrix_and_group64_agree(eng):
     s, rb, static_T = _arm_world("rightarm", TABLE)
     eng.upload_scene(s, static_T)
@@ -276,11 +324,12 @@ def test_empty_and_error_paths(eng):
     assert len(rec) == 0
     with pytest.raises(engine.EngineError):
         eng.set_contact_distance(-1.0)
-    sph = M.Scene()                                 # spheres: rejected loudly, never approximated
-    sph.add_object([(sph.add_sphere(0.1), M.IDENT7)], M.GROUP_KINBODY)
-    sph.finalize()
-    with pytest.raises(engine.EngineError, match="sphere"):
-        eng.upload_scene(sph, [M.IDENT7])
+    bad = M.Scene()                                 # an unknown shape kind: rejected loudly, never approximated
+    bad.add_object([(bad.add_sphere(0.1), M.IDENT7)], M.GROUP_KINBODY)
+    bad.finalize()
+    bad.arrays["kind"][0] = 7
+    with pytest.raises(engine.EngineError, match="kind 7"):
+        eng.upload_scene(bad, [M.IDENT7])
     eng.upload_scene(s, static_T)
     eng.upload_robot(rb)
     eng.set_capacity(16, 4)                         # too small on purpose: reported, not silently truncated
@@ -383,12 +432,12 @@ def test_ray_cast_golden_fixtures_bit_exact(eng):
     assert hits > 1000
 
 
-@pytest.mark.parametrize("seed,spread", [(600, 0.8), (601, 1.5), (602, 0.4), (603, 0.6)])
+@pytest.mark.parametrize("seed,spread", [(600, 0.8), (601, 1.5), (602, 0.4), (603, 0.6), (960, 0.6)])
 def test_ray_cast_random_scenes_vs_oracle(eng, seed, spread):
-    """boxes, hulls, z-cylinders (odd seeds), compounds: bit-exact against the oracle, which is bit-exact against the
-    reference's rayTest (tests/test_oracle_cpu.py)"""
+    """boxes, hulls, z-cylinders (odd seeds), spheres (seed 960), compounds: bit-exact against the oracle, which is
+    bit-exact against the reference's rayTest (tests/test_oracle_cpu.py)"""
     rng = np.random.default_rng(seed)
-    s, objT, robot = synth.random_scene(rng, spread=spread, n_static=8, n_robot=5, round_prob=0.3 if seed % 2 else 0.0)
+    s, objT, robot = synth.random_scene(rng, spread=spread, n_static=8, n_robot=5, round_prob=0.8 if seed >= 900 else (0.3 if seed % 2 else 0.0), spheres=seed >= 900)
     n = 2000
     a = rng.uniform(-1.5 * spread, 1.5 * spread, (n, 3))
     b = rng.uniform(-1.5 * spread, 1.5 * spread, (n, 3))

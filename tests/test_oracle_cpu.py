@@ -141,7 +141,7 @@ def test_ray_cast_golden_fixtures_bit_exact(built, mk):
 @pytest.mark.parametrize("seed", range(500, 512))
 def test_ray_cast_oracle_vs_reference_bullet(built, seed):
     """The C restatement and the host build of the device code against the reference's rayTest, bit for bit; seeds
-    3 mod 4 hold spheres (oracle only: the device narrowphase does not take them)."""
+    3 mod 4 hold spheres."""
     rng = np.random.default_rng(seed)
     spread = float(rng.choice([0.4, 0.8, 1.5]))
     spheres = seed % 4 == 3
@@ -151,7 +151,7 @@ def test_ray_cast_oracle_vs_reference_bullet(built, seed):
     b = rng.uniform(-1.5 * spread, 1.5 * spread, (n, 3))
     a[:20] = objT[rng.integers(0, len(objT), 20), 4:7]
     b[20:25] = a[20:25]
-    worlds = [B.ref_world(s), B.oracle_world(s)] + ([] if spheres else [util.emu_world(s)])
+    worlds = [B.ref_world(s), B.oracle_world(s), util.emu_world(s)]
     for d in (0.0, 0.05):
         for w in worlds:
             w.set_contact_distance(d)
@@ -192,11 +192,17 @@ def test_ray_cast_grazing_rays_and_the_reference_cull(built):
 
 
 @pytest.mark.skipif(not B.ref_available(), reason="oracle/_ref/libref.so is only built where /root/reference exists")
-@pytest.mark.parametrize("seed", list(range(100, 112)) + list(range(300, 308)))
+@pytest.mark.parametrize("seed", list(range(100, 112)) + list(range(300, 308)) + list(range(900, 912)))
 def test_oracle_vs_reference_bullet_random(built, seed):
-    """seeds >= 300: half of the shapes are z-cylinders (GT_Cylinder, bullet_collision_checker.cpp:153-158)"""
+    """seeds >= 300: half of the shapes are z-cylinders (GT_Cylinder, bullet_collision_checker.cpp:153-158); seeds >= 900:
+    crowded scenes, ~45 % spheres (GT_Sphere, :150-152): sphere vs box / hull / cylinder through GJK with the radius as
+    margin, sphere vs sphere through btSphereSphereCollisionAlgorithm (no contact while the surfaces are apart), swept
+    spheres, and the one cull of the reference that is not grown by d (swept sphere vs a compound's sphere child)."""
     rng = np.random.default_rng(seed)
-    s, objT, robot = synth.random_scene(rng, spread=float(rng.choice([0.3, 0.6])), round_prob=0.5 if seed >= 300 else 0.0)
+    if seed >= 900:
+        s, objT, robot = synth.random_scene(rng, spread=0.35, round_prob=0.9, spheres=True, n_static=8, n_robot=6)
+    else:
+        s, objT, robot = synth.random_scene(rng, spread=float(rng.choice([0.3, 0.6])), round_prob=0.5 if seed >= 300 else 0.0)
     wr, wo, we = B.ref_world(s), B.oracle_world(s), util.emu_world(s)
     T1 = objT[robot].copy()
     T1[:, 4:] += rng.normal(size=(len(robot), 3)) * 0.15
@@ -234,14 +240,15 @@ def test_reference_continuous_check_known_answer(built, mk):
 
 
 @pytest.mark.skipif(not B.ref_available(), reason="oracle/_ref/libref.so is only built where /root/reference exists")
-@pytest.mark.parametrize("seed", range(400, 412))
+@pytest.mark.parametrize("seed", list(range(400, 412)) + list(range(920, 926)))
 def test_continuous_check_oracle_vs_reference_bullet(built, seed):
     """ContinuousCheckTrajectory: the C restatement and the host build of the DEVICE code (emu) against the reference's
     own btCollisionWorld::convexSweepTest, bit for bit.  Where several objects share the smallest fraction (0: already
     touching at the start of the segment) the reference reports the first in DBVT order, which is history dependent;
     there its choice is checked pair by pair (ora_sweep_pair) instead."""
     rng = np.random.default_rng(seed)
-    s, objT, robot = synth.random_scene(rng, spread=float(rng.choice([0.4, 0.8, 1.5])), round_prob=0.3 if seed % 2 else 0.0)
+    s, objT, robot = synth.random_scene(rng, spread=float(rng.choice([0.4, 0.8, 1.5])), round_prob=0.3 if seed % 2 else 0.0, spheres=False) if seed < 900 else \
+        synth.random_scene(rng, spread=float(rng.choice([0.4, 0.8])), round_prob=0.8, spheres=True)   # seeds >= 900: ~40 % spheres
     nst = 4
     traj = np.stack([np.array([synth.random_T7(rng, -0.8, 0.8) for _ in robot]) for _ in range(nst)])
     wr, wo, we = B.ref_world(s), B.oracle_world(s), util.emu_world(s)

@@ -452,6 +452,8 @@ int tohc_upload_scene(tohc_engine *e, int n_shapes, const int32_t *shape_kind, c
     const float *p = shape_param + 4 * i;
     if (shape_kind[i] == TOHC_BOX) {
       if (!(p[0] > 0 && p[1] > 0 && p[2] > 0)) return fail(e, TOHC_E_INVALID, "upload_scene: box %d has non-positive extents", i);
+    } else if (shape_kind[i] == TOHC_SPHERE) {
+      if (!(p[0] > 0)) return fail(e, TOHC_E_INVALID, "upload_scene: sphere %d has a non-positive radius", i);
     } else if (shape_kind[i] == TOHC_CYLZ) {
       if (!(p[0] > 0 && p[1] > 0)) return fail(e, TOHC_E_INVALID, "upload_scene: cylinder %d has a non-positive radius or height", i);
     } else if (shape_kind[i] == TOHC_HULL) {
@@ -459,7 +461,7 @@ int tohc_upload_scene(tohc_engine *e, int n_shapes, const int32_t *shape_kind, c
           (int64_t)shape_voff[i] + shape_vcnt[i] > n_verts)
         return fail(e, TOHC_E_INVALID, "upload_scene: hull %d has a bad vertex range (1..64 vertices supported)", i);
     } else {
-      return fail(e, TOHC_E_UNSUPPORTED, "upload_scene: shape %d has kind %d; boxes, z-cylinders and convex hulls are supported (spheres: Bullet's sphere-specific algorithms are not restated)", i, shape_kind[i]);
+      return fail(e, TOHC_E_UNSUPPORTED, "upload_scene: shape %d has kind %d; boxes, spheres, z-cylinders and convex hulls are supported", i, shape_kind[i]);
     }
   }
   for (int c = 0; c < n_children; ++c)
@@ -496,6 +498,10 @@ int tohc_upload_scene(tohc_engine *e, int n_shapes, const int32_t *shape_kind, c
         float dim = ((p[k] * 1.0f - m) + m) - 0.0f;
         e->h_shape_dims[3 * i + k] = dim; e->h_shape_lmin[3 * i + k] = -dim; e->h_shape_lmax[3 * i + k] = dim;
       }
+    } else if (shape_kind[i] == TOHC_SPHERE) {
+      // btSphereShape(radius): m_implicitShapeDimensions.x = radius, getMargin() = getRadius() whatever setMargin(0) did
+      // (btSphereShape.h:29-67); local box = centre +- radius
+      for (int k = 0; k < 3; ++k) { e->h_shape_dims[3 * i + k] = p[0]; e->h_shape_lmin[3 * i + k] = -p[0]; e->h_shape_lmax[3 * i + k] = p[0]; }
     } else if (shape_kind[i] == TOHC_CYLZ) {
       // btCylinderShapeZ(r, r, h/2): same margin round trip as the box (btCylinderShape.cpp:18-27); param = (radius, half height)
       const float he[3] = {p[0], p[0], p[1]};
@@ -527,6 +533,8 @@ int tohc_upload_scene(tohc_engine *e, int n_shapes, const int32_t *shape_kind, c
         const double dx = (double)vx[v] - c[0], dy = (double)vy[v] - c[1], dz = (double)vz[v] - c[2];
         r2 = std::max(r2, (float)(dx * dx + dy * dy + dz * dz));
       }
+    } else if (shape_kind[i] == TOHC_SPHERE) {
+      r2 = e->h_shape_dims[3 * i] * e->h_shape_dims[3 * i];
     } else {   // box / cylinder: the corner of the local box
       for (int k = 0; k < 3; ++k) { const double h = (double)e->h_shape_lmax[3 * i + k] - c[k]; r2 += (float)(h * h); }
     }

@@ -482,7 +482,8 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
         if (dl2 > 1.0e-12f) {
           const float dl = sqrtf(dl2);
           const V3 pA = xfApply(tq, supNV<1>(cq, mulVM(-dir, tq.b)));
-          const float deltaS = dot(dir, pA - c) - rad * dl;
+          const float mq = cvxMargin<1>(cq);   // a plain sphere is its centre + this much (0 for everything else)
+          const float deltaS = dot(dir, pA - c) - (rad + mq) * dl;
           if ((deltaS > 0.0f && deltaS > lim * dl) || ca.dbg == 2) {
             keep = false;
           } else if (TOHC_BP_EXACT) {
@@ -493,7 +494,8 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
             cvxLoad<1>(cx, dx.kind, mk(dx.dims[0], dx.dims[1], dx.dims[2]), sc.vx, sc.vy, sc.vz, sc.v4, dx.voff, dx.vcnt);
             const V3 qB = xfApply(tx, supNV<1>(cx, mulVM(dir, tx.b)));
             const float delta = dot(dir, pA - qB);
-            keep = !((delta > 0.0f) && (delta * delta > (lim * lim) * dl2));
+            const float limm = lim + (mq + cvxMargin<1>(cx));
+            keep = !((delta > 0.0f) && (delta * delta > (limm * limm) * dl2));
           }
         }
       }
@@ -792,6 +794,19 @@ __device__ __forceinline__ void writeHit(const NarrowArgs &a, int shard, unsigne
     a.cnt->overflow = 1;
   }
 }
+// a finished pair evaluation: `o` goes to the hit list when it is a contact the collector keeps.  Call with every lane
+// of the (possibly divergent) branch: the lane-per-pair kernels reserve their slots with one atomic per wavefront.
+template <int G>
+__device__ __forceinline__ void pushOut(const NarrowArgs &a, unsigned int pairPos, const PairOut &o) {
+  const bool hit = o.valid && !((double)o.distance > (double)a.cp.d);
+  const int shard = blockIdx.x % TOHC_NSHARD;
+  if (G == 1) {
+    const unsigned int slot = waveSlot(&a.cnt->sh[shard].n_hits, hit);
+    if (hit) writeHit(a, shard, slot, pairPos, o);
+  } else if (hit && Grp<G>::lane() == 0) {
+    writeHit(a, shard, atomicAdd(&a.cnt->sh[shard].n_hits, 1u), pairPos, o);
+  }
+}
 template <int G>
 __device__ __forceinline__ void pushIfContact(const NarrowArgs &a, unsigned int pairPos, const GjkState &st, float md2) {
   PairOut o;
@@ -821,7 +836,7 @@ __global__ void __launch_bounds__(BLOCK, TOHC_GJK_WAVES) k_gjk(NarrowArgs a) {
   qprefix(&a.cnt->sh[0].n_pairs, a.cp.seg_cap, pre);
   const unsigned int npairs = pre.start[TOHC_NSHARD];
   float md2 = a.cp.breaking;
-  md2 *= md2;  // (marginA + marginB + gContactBreakingThreshold)^2 with zero margins [cca:370-373]
+  md2 *= md2;  // (marginA + marginB + gContactBreakingThreshold)^2 [cca:370-373]; re-made per pair when a margin is not 0
   const int maxIter = a.cp.dbg_max_iter;
   // operands live in their GJK roles; the query child stays in its role register across pairs when it can
   Cvx<G> cA, cB;
@@ -860,7 +875,17 @@ __global__ void __launch_bounds__(BLOCK, TOHC_GJK_WAVES) k_gjk(NarrowArgs a) {
         if (needQ) loadSide<G>(a, pr.q, a.sc.child_desc[pr.q], set0, set1, CAST, cA, tA);
       }
       lastQ = pr.q; lastSet = pr.set; qInB = xIsA;
-      g.init(tA, tB);
+      md2 = pairMaxDist2<G>(cA, cB, a.cp.breaking);
+      if (isSphereSphere<G>(cA, cB)) {   // discrete, both plain spheres: Bullet's analytic algorithm, no GJK
+        PairOut o;
+        sphereSphere(tA.o, cA.margin, tB.o, cB.margin, o);
+        pushOut<G>(a, pos, o);
+        continue;
+      }
+      if (CAST && xIsA && cA.kind == KIND_SPHERE && cB.kind == KIND_SPHERE &&
+          castSphereChildCulled(tB.o, xfApply(tB, cB.t01.o), cB.margin, tA.o, cA.margin))
+        continue;   // the reference's child-box test removes this pair before GJK (see castSphereChildCulled)
+      g.init(tA, tB, cvxMargin<G>(cA), cvxMargin<G>(cB));
       active = true;
     }
     if (Grp<G>::lane() == 0) ++steps;
@@ -917,6 +942,7 @@ __device__ __forceinline__ void loadQueued(const NarrowArgs &a, const EpaRec &e,
   st.pointOnB = mk(e.pB[0], e.pB[1], e.pB[2]);
   st.offset = (tA.o + tB.o) * 0.5f;
   st.iters = 0;
+  st.mA = cvxMargin<G>(A); st.mB = cvxMargin<G>(B);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -965,6 +991,7 @@ __global__ void __launch_bounds__(64, TOHC_PEN_WAVES) k_tail_pen(TailArgs ta) {
     Xf tA, tB, lA, lB;
     GjkState st;
     loadQueued<G>(a, e, cast, A, B, tA, tB, st);
+    md2 = pairMaxDist2<G>(A, B, a.cp.breaking);
     penLocal(tA, tB, st.offset, lA, lB);
     V3 tmpA = mk(0, 0, 0), tmpB = mk(0, 0, 0), sep = mk(0, 0, 0);
     bool isValid2 = false;
@@ -1024,6 +1051,7 @@ __global__ void __launch_bounds__(BLOCK, TOHC_EPA_WAVES) k_tail_epa(TailArgs ta)
       Xf tA, tB, lA, lB;
       GjkState st;
       loadQueued<G>(a, e, a.cp.cast != 0, A, B, tA, tB, st);
+      md2 = pairMaxDist2<G>(A, B, a.cp.breaking);
       penLocal(tA, tB, st.offset, lA, lB);
       Gjk2<G, EpaMem> g;
       penRestore<G>(m, r->h, A, B, lA, lB, g);

@@ -11,8 +11,9 @@
 //   [vss] .../btVoronoiSimplexSolver.cpp:35-608            [epa] .../btGjkEpa2.cpp:142-945
 //   [pds] .../btGjkEpaPenetrationDepthSolver.cpp:24-64     [cvx] .../CollisionShapes/btConvexShape.cpp:64-308
 //   [bcc] src/trajopt/bullet_collision_checker.cpp:98-131 (GetAverageSupport), :816-882 (CastHullShape), :894-972
-// Margins: boxes and hulls carry margin 0 (MARGIN, bcc:23), so the "+ margin * n" terms of the reference are exact
-// no-ops and are left out; sphere / cylinder geometry is not supported yet (tohc_upload_scene rejects it).
+// Margins: boxes, hulls and cylinders carry margin 0 (MARGIN, bcc:23), so for them the "+ margin * n" terms of the
+// reference are exact no-ops and are skipped; a sphere is the point at its origin with margin = radius
+// (btSphereShape.h:62-67), and every margin term of the reference is applied when a margin is not zero.
 #pragma once
 #include <float.h>
 #include <limits.h>
@@ -91,13 +92,14 @@ struct Grp<1> {  // one lane per pair: nothing to exchange
 };
 #endif
 
-enum { KIND_BOX = 0, KIND_HULL = 1, KIND_CYLZ = 3 };   // 2 = sphere: not supported (tohc_upload_scene rejects it)
+enum { KIND_BOX = 0, KIND_HULL = 1, KIND_SPHERE = 2, KIND_CYLZ = 3 };
 
 template <int G>
 struct Cvx {
   static constexpr int VPL = 64 / G;
   int kind, cast, n;
-  V3 dims;  // box: m_implicitShapeDimensions after the margin round trip (host computes it, engine.hip)
+  V3 dims;  // box: m_implicitShapeDimensions after the margin round trip (host computes it, engine.hip); sphere: (r, r, r)
+  float margin;   // getMargin(): the radius of a sphere, else 0
   float x[VPL], y[VPL], z[VPL];
   Xf t01;   // cast: T_0_1 = T_w_0^-1 * T_w_1
 };
@@ -107,6 +109,7 @@ template <>
 struct Cvx<1> {
   int kind, cast, n;
   V3 dims;
+  float margin;
   const F4 *v;
   Xf t01;
 };
@@ -117,6 +120,7 @@ TOHC_DEV void cvxLoad(Cvx<G> &c, int kind, V3 dims, const float *vx, const float
   c.cast = 0;
   c.n = n;
   c.dims = dims;
+  c.margin = kind == KIND_SPHERE ? dims.x * 1.0f : 0.0f;   // getRadius() = m_implicitShapeDimensions.x * m_localScaling.x
   const int gl = Grp<G>::lane();
 #pragma unroll
   for (int s = 0; s < Cvx<G>::VPL; ++s) {
@@ -141,6 +145,7 @@ TOHC_DEV void cvxLoad<1>(Cvx<1> &c, int kind, V3 dims, const float *, const floa
   c.cast = 0;
   c.n = n;
   c.dims = dims;
+  c.margin = kind == KIND_SPHERE ? dims.x * 1.0f : 0.0f;   // getRadius() = m_implicitShapeDimensions.x * m_localScaling.x
   c.v = v4 + voff;
 }
 
@@ -216,8 +221,13 @@ TOHC_DEV V3 cvxVertex<1>(const Cvx<1> &c, int i) {
 }
 
 // localGetSupportVertexWithoutMarginNonVirtual for box / hull [cvx:120-296]
+TOHC_DEV V3 normalizedOrMinus1(V3 d) {  // [cvx:298-306], btSphereShape.cpp:43-48
+  if (len2(d) < (FLT_EPSILON * FLT_EPSILON)) d = mk(-1, -1, -1);
+  return vdiv(d, len(d));
+}
 template <int G>
 TOHC_DEV V3 supPlainNV(const Cvx<G> &c, V3 d) {
+  if (c.kind == KIND_SPHERE) return mk(0, 0, 0);   // [cvx:125-128]
   if (c.kind == KIND_BOX) return mk(fsel(-d.x, -c.dims.x, c.dims.x), fsel(-d.y, -c.dims.y, c.dims.y), fsel(-d.z, -c.dims.z, c.dims.z));
   if (c.kind == KIND_CYLZ) return cylZSupport(c.dims, d);
   return hullMaxDot<G>(c, d);
@@ -225,6 +235,7 @@ TOHC_DEV V3 supPlainNV(const Cvx<G> &c, V3 d) {
 // the VIRTUAL localGetSupportingVertex CastHullShape calls on its inner shape: box tie rule d >= 0 -> +h (btBoxShape.h:50-59)
 template <int G>
 TOHC_DEV V3 supPlainVirtual(const Cvx<G> &c, V3 d) {
+  if (c.kind == KIND_SPHERE) return normalizedOrMinus1(d) * c.margin;   // btSphereShape::localGetSupportingVertex (btSphereShape.cpp:38-53)
   if (c.kind == KIND_BOX) return mk(fsel(d.x, c.dims.x, -c.dims.x), fsel(d.y, c.dims.y, -c.dims.y), fsel(d.z, c.dims.z, -c.dims.z));
   if (c.kind == KIND_CYLZ) return cylZSupport(c.dims, d);   // btCylinderShape's virtual support + margin 0
   return hullMaxDot<G>(c, d);
@@ -236,12 +247,18 @@ TOHC_DEV V3 supNV(const Cvx<G> &c, V3 d) {
   V3 sv1 = xfApply(c.t01, supPlainVirtual<G>(c, mulVM(d, c.t01.b)));
   return (dot(d, sv0) > dot(d, sv1)) ? sv0 : sv1;
 }
-TOHC_DEV V3 normalizedOrMinus1(V3 d) {  // [cvx:298-306]
-  if (len2(d) < (FLT_EPSILON * FLT_EPSILON)) d = mk(-1, -1, -1);
-  return vdiv(d, len(d));
-}
+// getMarginNonVirtual() of a GJK operand: the swept shape's is 0 (CastHullShape::getMargin, bcc:870)
 template <int G>
-TOHC_DEV V3 supWithMarginNV(const Cvx<G> &c, V3 d) { return supNV<G>(c, normalizedOrMinus1(d)); }
+TOHC_DEV float cvxMargin(const Cvx<G> &c) { return c.cast ? 0.0f : c.margin; }
+// localGetSupportVertexNonVirtual [cvx:298-308]
+template <int G>
+TOHC_DEV V3 supWithMarginNV(const Cvx<G> &c, V3 d) {
+  const V3 n = normalizedOrMinus1(d);
+  const float m = cvxMargin<G>(c);
+  V3 s = supNV<G>(c, n);
+  if (m != 0.0f) s = s + n * m;
+  return s;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // btVoronoiSimplexSolver [vss]; arrays are only ever indexed with compile-time constants (select chains), so they
@@ -512,6 +529,7 @@ struct GjkState {
   V3 normalInB, pointOnB;   // pointOnB in the midpoint-shifted frame
   V3 offset;
   int iters;
+  float mA, mB;   // the operands' margins (0 except for plain spheres)
 };
 
 // The loop of getClosestPointsNonVirtual as a resumable object: init(), step() until it returns true, finish().
@@ -522,10 +540,12 @@ struct GjkRun {
   Simplex sx;
   V3 sep, offset, oA, oB;
   float squaredDistance;
+  float mA, mB;
   int curIter, degenerate;
   bool checkSimplex;
 
-  TOHC_DEV void init(const Xf &tA, const Xf &tB) {
+  TOHC_DEV void init(const Xf &tA, const Xf &tB, float marginA, float marginB) {
+    mA = marginA; mB = marginB;
     offset = (tA.o + tB.o) * 0.5f;
     oA = tA.o - offset;
     oB = tB.o - offset;
@@ -578,11 +598,17 @@ struct GjkRun {
       if (lenSqr > FLT_EPSILON * FLT_EPSILON) {
         float rlen = 1.0f / sqrtf(lenSqr);
         normalInB = normalInB * rlen;
-        distance = (1.0f / rlen);
+        if (mA != 0.0f || mB != 0.0f) {   // [gjk:318-325]; with zero margins these are exact no-ops
+          const float s = sqrtf(squaredDistance);
+          pointOnB = pointOnB + sep * (mB / s);
+          distance = (1.0f / rlen) - (mA + mB);
+        } else {
+          distance = (1.0f / rlen);
+        }
         isValid = true;
       }
     }
-    bool catchDeg = degenerate && ((double)distance < 0.01);
+    bool catchDeg = degenerate && ((double)(distance + (mA + mB)) < 0.01);
     st.isValid = isValid;
     st.needEpa = (!isValid || catchDeg);
     st.distance = distance;
@@ -590,6 +616,7 @@ struct GjkRun {
     st.pointOnB = pointOnB;
     st.offset = offset;
     st.iters = curIter;
+    st.mA = mA; st.mB = mB;
   }
 };
 
@@ -604,13 +631,14 @@ TOHC_DEV bool sepAxisBeyond(const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, cons
   V3 qB = xfApply(tB, supNV<G>(B, mulVM(dir, tB.b)));
   w = pA - qB;
   float delta = dot(dir, w);
-  return (delta > 0.0f) && (delta * delta > (lim * lim) * len2(dir));
+  const float limm = lim + (cvxMargin<G>(A) + cvxMargin<G>(B));   // the supports are those of the cores: a plain sphere reaches its radius further
+  return (delta > 0.0f) && (delta * delta > (limm * limm) * len2(dir));
 }
 
 template <int G>
 TOHC_DEV void gjkMain(const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &tB, float maxDist2, GjkState &st, int maxIter = 1000) {
   GjkRun<G> r;
-  r.init(tA, tB);
+  r.init(tA, tB, cvxMargin<G>(A), cvxMargin<G>(B));
   while (!r.step(A, B, tA, tB, maxDist2, maxIter)) {}
   r.finish(st);
 }
@@ -1310,6 +1338,42 @@ struct PairOut {
   float distance;
 };
 
+// (marginA + marginB + gContactBreakingThreshold)^2: the pair detector's m_maximumDistanceSquared [cca:370-373]
+template <int G>
+TOHC_DEV float pairMaxDist2(const Cvx<G> &A, const Cvx<G> &B, float breaking) {
+  float md = cvxMargin<G>(A) + cvxMargin<G>(B) + breaking;
+  return md * md;
+}
+// Two PLAIN spheres never reach GJK: the dispatch matrix holds btSphereSphereCollisionAlgorithm for that pair of shape
+// types (btDefaultCollisionConfiguration.cpp:219-222; a compound's child is dispatched by the child's type,
+// btCompoundCollisionAlgorithm.cpp:65).  A swept sphere is a CastHullShape, a custom convex type: that one goes to GJK.
+template <int G>
+TOHC_DEV bool isSphereSphere(const Cvx<G> &A, const Cvx<G> &B) { return A.kind == KIND_SPHERE && B.kind == KIND_SPHERE && !A.cast && !B.cast; }
+// btSphereSphereCollisionAlgorithm::processCollision (btSphereSphereCollisionAlgorithm.cpp:42-89): no contact at all
+// while the surfaces are apart
+TOHC_DEV void sphereSphere(V3 oA, float radius0, V3 oB, float radius1, PairOut &o) {
+  o.valid = false;
+  const V3 diff = oA - oB;
+  const float l = len(diff);
+  if (l > (radius0 + radius1)) return;
+  o.distance = l - (radius0 + radius1);
+  o.normalOnB = mk(1, 0, 0);
+  if (l > FLT_EPSILON) o.normalOnB = vdiv(diff, l);
+  o.pointOnB = oB + o.normalOnB * radius1;
+  o.valid = true;
+}
+// The one pair kind whose reference cull is not grown by d on either side: a swept sphere against the sphere child of
+// a COMPOUND.  The compound's child test [btCompoundCollisionAlgorithm.cpp:128-132] takes btSphereShape::getAabb
+// (centre +- radius; the SHAPE_EXPANSION patch sits in btTransformAabb, which spheres do not call) for the child and
+// CastHullShape::getAabb [bcc:850-856] = the union of the same at both ends of the sweep for the swept sphere; pairs it
+// rejects never reach GJK, though GJK would report a contact at a distance in (0, d].  true = the reference culls.
+TOHC_DEV bool castSphereChildCulled(V3 o0, V3 o1, float rq, V3 ox, float rx) {
+  const V3 q = mk(rq, rq, rq), x = mk(rx, rx, rx);
+  Aabb bs = aabbUnion(Aabb{o0 - q, o0 + q}, Aabb{o1 - q, o1 + q});
+  Aabb bc{ox - x, ox + x};
+  return !aabbOverlap(bs, bc);
+}
+
 // [gjk:349-416] what getClosestPointsNonVirtual does with calcPenDepth's answer
 TOHC_DEV void gjkFinishTail(bool isValid2, V3 sep, V3 tmpA, V3 tmpB, GjkState &st) {
   if (isValid2) {
@@ -1325,10 +1389,11 @@ TOHC_DEV void gjkFinishTail(bool isValid2, V3 sep, V3 tmpA, V3 tmpB, GjkState &s
     }
   } else {
     if (len2(sep) > 0.0f) {
-      float distance2 = len(tmpA - tmpB);
+      const float margin = st.mA + st.mB;
+      float distance2 = margin != 0.0f ? len(tmpA - tmpB) - margin : len(tmpA - tmpB);
       if (!st.isValid || (distance2 < st.distance)) {
         st.distance = distance2;
-        st.pointOnB = tmpB;
+        st.pointOnB = st.mB != 0.0f ? tmpB + sep * st.mB : tmpB;   // [gjk:404-405]
         st.normalInB = vdiv(sep, len(sep));
         st.isValid = true;
       }
@@ -1411,8 +1476,8 @@ TOHC_DEV void avgHull<1>(const Cvx<1> &c, V3 nl, AvgAcc &a) {
 }
 template <int G>
 TOHC_DEV void averageSupport(const Cvx<G> &c, V3 nl, float &outsup, V3 &outpt) {
-  if (c.kind == KIND_CYLZ) {  // not polyhedral: the support vertex itself [bcc:124-129]
-    outpt = cylZSupport(c.dims, nl);
+  if (c.kind == KIND_CYLZ || c.kind == KIND_SPHERE) {  // not polyhedral: localGetSupportingVertexWithoutMargin itself [bcc:124-129]
+    outpt = c.kind == KIND_SPHERE ? mk(0, 0, 0) : cylZSupport(c.dims, nl);
     outsup = dot(nl, outpt);
     return;
   }
@@ -1624,7 +1689,10 @@ TOHC_DEV Xf integrateTransform(const Xf &cur, V3 linvel, V3 angvel, float timeSt
 // SHAPE_EXPANSION (= d); a hull's cached local box still carries the 0.04 construction margin
 TOHC_DEV float angularMotionDisc(int kind, V3 dims, V3 lmin, V3 lmax, float d) {
   V3 mn, mx;
-  if (kind == KIND_HULL) {
+  if (kind == KIND_SPHERE) {   // btSphereShape::getAabb: centre +- margin, untouched by the SHAPE_EXPANSION patch
+    const float m = dims.x * 1.0f;
+    mn = mk(0 - m, 0 - m, 0 - m); mx = mk(0 + m, 0 + m, 0 + m);
+  } else if (kind == KIND_HULL) {
     const float CDM = 0.04f;
     const V3 hi = mk(lmax.x + CDM, lmax.y + CDM, lmax.z + CDM), lo = mk(lmin.x - CDM, lmin.y - CDM, lmin.z - CDM);
     V3 he = (hi - lo) * 0.5f;
