@@ -43,7 +43,7 @@ bool pairEval(World *w, const Cvx<1> &A, const Xf &tA, const Cvx<1> &B, const Xf
   w->pair_evals++;
   if (isSphereSphere<1>(A, B)) {   // as k_gjk does
     PairOut o;
-    sphereSphere(tA.o, A.margin, tB.o, B.margin, o);
+    sphereSphere(tA.o, shapeMargin<1>(A), tB.o, shapeMargin<1>(B), o);
     if (!o.valid || (double)o.distance > (double)w->d) return false;
     V3 pA = o.pointOnB + o.normalOnB * o.distance;
     c->dist = o.distance;
@@ -209,7 +209,7 @@ int emu_cast_vs_all(void *h, const double *objT7, const int *q, int nq, const do
           ora_contact c;
           memset(&c, 0, sizeof c);
           bool kept, castFirst;
-          if (w->compound[X] && cq.kind == KIND_SPHERE && cx.kind == KIND_SPHERE && castSphereChildCulled(tf0.o, xfApply(tf0, cq.t01.o), cq.margin, tx.o, cx.margin)) {
+          if (w->compound[X] && cq.kind == KIND_SPHERE && cx.kind == KIND_SPHERE && castSphereChildCulled(tf0.o, xfApply(tf0, cq.t01.o), shapeMargin<1>(cq), tx.o, shapeMargin<1>(cx))) {
             w->pair_evals++;   // as k_gjk does: the evaluation ends at the reference's child-box test
             continue;
           }

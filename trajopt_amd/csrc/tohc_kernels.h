@@ -835,8 +835,6 @@ __global__ void __launch_bounds__(BLOCK, TOHC_GJK_WAVES) k_gjk(NarrowArgs a) {
   QPrefix pre;
   qprefix(&a.cnt->sh[0].n_pairs, a.cp.seg_cap, pre);
   const unsigned int npairs = pre.start[TOHC_NSHARD];
-  float md2 = a.cp.breaking;
-  md2 *= md2;  // (marginA + marginB + gContactBreakingThreshold)^2 [cca:370-373]; re-made per pair when a margin is not 0
   const int maxIter = a.cp.dbg_max_iter;
   // operands live in their GJK roles; the query child stays in its role register across pairs when it can
   Cvx<G> cA, cB;
@@ -875,23 +873,25 @@ __global__ void __launch_bounds__(BLOCK, TOHC_GJK_WAVES) k_gjk(NarrowArgs a) {
         if (needQ) loadSide<G>(a, pr.q, a.sc.child_desc[pr.q], set0, set1, CAST, cA, tA);
       }
       lastQ = pr.q; lastSet = pr.set; qInB = xIsA;
-      md2 = pairMaxDist2<G>(cA, cB, a.cp.breaking);
       if (isSphereSphere<G>(cA, cB)) {   // discrete, both plain spheres: Bullet's analytic algorithm, no GJK
         PairOut o;
-        sphereSphere(tA.o, cA.margin, tB.o, cB.margin, o);
+        sphereSphere(tA.o, shapeMargin<G>(cA), tB.o, shapeMargin<G>(cB), o);
         pushOut<G>(a, pos, o);
         continue;
       }
       if (CAST && xIsA && cA.kind == KIND_SPHERE && cB.kind == KIND_SPHERE &&
-          castSphereChildCulled(tB.o, xfApply(tB, cB.t01.o), cB.margin, tA.o, cA.margin))
+          castSphereChildCulled(tB.o, xfApply(tB, cB.t01.o), shapeMargin<G>(cB), tA.o, shapeMargin<G>(cA)))
         continue;   // the reference's child-box test removes this pair before GJK (see castSphereChildCulled)
-      g.init(tA, tB, cvxMargin<G>(cA), cvxMargin<G>(cB));
+      g.init(tA, tB);
       active = true;
     }
     if (Grp<G>::lane() == 0) ++steps;
-    if (g.step(cA, cB, tA, tB, md2, maxIter)) {
+    // (marginA + marginB + gContactBreakingThreshold)^2 [cca:370-373]: re-made from the operands where it is used, so
+    // that it takes no register of its own across the loop (with zero margins it is the launch-wide constant)
+    const float md2p = pairMaxDist2<G>(cA, cB, a.cp.breaking);
+    if (g.step(cA, cB, tA, tB, md2p, maxIter)) {
       GjkState st;
-      g.finish(st);
+      g.finish(st, cvxMargin<G>(cA), cvxMargin<G>(cB));
       active = false;
       const int shard = blockIdx.x % TOHC_NSHARD;
       unsigned int slot = 0;
@@ -915,7 +915,7 @@ __global__ void __launch_bounds__(BLOCK, TOHC_GJK_WAVES) k_gjk(NarrowArgs a) {
       // (every lane that finished in this step takes part in the vote inside; pairs on their way to EPA are no contact yet)
       GjkState sh = st;
       if (st.needEpa) sh.isValid = false;
-      pushIfContact<G>(a, pos, sh, md2);
+      pushIfContact<G>(a, pos, sh, md2p);
     }
   }
   waveAdd(&a.cnt->sh[blockIdx.x % TOHC_NSHARD].n_gjk_steps, steps);

@@ -99,7 +99,6 @@ struct Cvx {
   static constexpr int VPL = 64 / G;
   int kind, cast, n;
   V3 dims;  // box: m_implicitShapeDimensions after the margin round trip (host computes it, engine.hip); sphere: (r, r, r)
-  float margin;   // getMargin(): the radius of a sphere, else 0
   float x[VPL], y[VPL], z[VPL];
   Xf t01;   // cast: T_0_1 = T_w_0^-1 * T_w_1
 };
@@ -109,7 +108,6 @@ template <>
 struct Cvx<1> {
   int kind, cast, n;
   V3 dims;
-  float margin;
   const F4 *v;
   Xf t01;
 };
@@ -120,7 +118,6 @@ TOHC_DEV void cvxLoad(Cvx<G> &c, int kind, V3 dims, const float *vx, const float
   c.cast = 0;
   c.n = n;
   c.dims = dims;
-  c.margin = kind == KIND_SPHERE ? dims.x * 1.0f : 0.0f;   // getRadius() = m_implicitShapeDimensions.x * m_localScaling.x
   const int gl = Grp<G>::lane();
 #pragma unroll
   for (int s = 0; s < Cvx<G>::VPL; ++s) {
@@ -145,7 +142,6 @@ TOHC_DEV void cvxLoad<1>(Cvx<1> &c, int kind, V3 dims, const float *, const floa
   c.cast = 0;
   c.n = n;
   c.dims = dims;
-  c.margin = kind == KIND_SPHERE ? dims.x * 1.0f : 0.0f;   // getRadius() = m_implicitShapeDimensions.x * m_localScaling.x
   c.v = v4 + voff;
 }
 
@@ -221,6 +217,10 @@ TOHC_DEV V3 cvxVertex<1>(const Cvx<1> &c, int i) {
 }
 
 // localGetSupportVertexWithoutMarginNonVirtual for box / hull [cvx:120-296]
+// getMargin() of the plain shape: a sphere's radius (getRadius() = m_implicitShapeDimensions.x * m_localScaling.x,
+// btSphereShape.h:62-67), 0 for everything else (MARGIN, bcc:23).  Derived on demand: no register of its own.
+template <int G>
+TOHC_DEV float shapeMargin(const Cvx<G> &c) { return c.kind == KIND_SPHERE ? c.dims.x * 1.0f : 0.0f; }
 TOHC_DEV V3 normalizedOrMinus1(V3 d) {  // [cvx:298-306], btSphereShape.cpp:43-48
   if (len2(d) < (FLT_EPSILON * FLT_EPSILON)) d = mk(-1, -1, -1);
   return vdiv(d, len(d));
@@ -235,7 +235,7 @@ TOHC_DEV V3 supPlainNV(const Cvx<G> &c, V3 d) {
 // the VIRTUAL localGetSupportingVertex CastHullShape calls on its inner shape: box tie rule d >= 0 -> +h (btBoxShape.h:50-59)
 template <int G>
 TOHC_DEV V3 supPlainVirtual(const Cvx<G> &c, V3 d) {
-  if (c.kind == KIND_SPHERE) return normalizedOrMinus1(d) * c.margin;   // btSphereShape::localGetSupportingVertex (btSphereShape.cpp:38-53)
+  if (c.kind == KIND_SPHERE) return normalizedOrMinus1(d) * (c.dims.x * 1.0f);   // btSphereShape::localGetSupportingVertex (btSphereShape.cpp:38-53)
   if (c.kind == KIND_BOX) return mk(fsel(d.x, c.dims.x, -c.dims.x), fsel(d.y, c.dims.y, -c.dims.y), fsel(d.z, c.dims.z, -c.dims.z));
   if (c.kind == KIND_CYLZ) return cylZSupport(c.dims, d);   // btCylinderShape's virtual support + margin 0
   return hullMaxDot<G>(c, d);
@@ -249,7 +249,7 @@ TOHC_DEV V3 supNV(const Cvx<G> &c, V3 d) {
 }
 // getMarginNonVirtual() of a GJK operand: the swept shape's is 0 (CastHullShape::getMargin, bcc:870)
 template <int G>
-TOHC_DEV float cvxMargin(const Cvx<G> &c) { return c.cast ? 0.0f : c.margin; }
+TOHC_DEV float cvxMargin(const Cvx<G> &c) { return c.cast ? 0.0f : shapeMargin<G>(c); }
 // localGetSupportVertexNonVirtual [cvx:298-308]
 template <int G>
 TOHC_DEV V3 supWithMarginNV(const Cvx<G> &c, V3 d) {
@@ -540,12 +540,10 @@ struct GjkRun {
   Simplex sx;
   V3 sep, offset, oA, oB;
   float squaredDistance;
-  float mA, mB;
   int curIter, degenerate;
   bool checkSimplex;
 
-  TOHC_DEV void init(const Xf &tA, const Xf &tB, float marginA, float marginB) {
-    mA = marginA; mB = marginB;
+  TOHC_DEV void init(const Xf &tA, const Xf &tB) {
     offset = (tA.o + tB.o) * 0.5f;
     oA = tA.o - offset;
     oB = tB.o - offset;
@@ -584,8 +582,8 @@ struct GjkRun {
     if (sx.n == 4) { degenerate = 13; return true; }
     return false;
   }
-  // [gjk:304-335]
-  TOHC_DEV void finish(GjkState &st) {
+  // [gjk:304-335]; mA / mB: the operands' margins (cvxMargin)
+  TOHC_DEV void finish(GjkState &st, float mA, float mB) {
     float distance = 0;
     V3 normalInB = mk(0, 0, 0), pointOnB = mk(0, 0, 0);
     bool isValid = false;
@@ -638,9 +636,9 @@ TOHC_DEV bool sepAxisBeyond(const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, cons
 template <int G>
 TOHC_DEV void gjkMain(const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &tB, float maxDist2, GjkState &st, int maxIter = 1000) {
   GjkRun<G> r;
-  r.init(tA, tB, cvxMargin<G>(A), cvxMargin<G>(B));
+  r.init(tA, tB);
   while (!r.step(A, B, tA, tB, maxDist2, maxIter)) {}
-  r.finish(st);
+  r.finish(st, cvxMargin<G>(A), cvxMargin<G>(B));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
