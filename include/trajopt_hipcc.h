@@ -40,6 +40,10 @@ enum { TOHC_BOX = 0, TOHC_HULL = 1, TOHC_SPHERE = 2, TOHC_CYLZ = 3 };  /* create
 enum { TOHC_GROUP_ROBOT = 1, TOHC_GROUP_KINBODY = 2 };  /* CollisionFilterGroups, collision_checker.hpp:32-35        */
 enum { TOHC_CC_NONE = 0, TOHC_CC_TIME0 = 1, TOHC_CC_TIME1 = 2, TOHC_CC_BETWEEN = 3 }; /* CastCollisionType, :12-17  */
 enum { TOHC_J_FIXED = 0, TOHC_J_REVOLUTE = 1, TOHC_J_PRISMATIC = 2 };
+/* dof[i] of a TOHC_J_FIXED link: the link of a body the robot has GRABBED, hanging off its grabber link (T_origin = the
+ * pose in the grabber's frame).  RobotAndDOF::GetAffectedLinks lists such links unconditionally, with the grabber's index
+ * as their Jacobian link (configuration_space.cpp:120-131): they are query links even when no active DOF moves them. */
+#define TOHC_DOF_GRABBED (-2)
 enum { TOHC_DOF_X = 1, TOHC_DOF_Y = 2, TOHC_DOF_Z = 4, TOHC_DOF_ROTAXIS = 8 }; /* OpenRAVE DOFAffine, configuration_space.cpp:47-78 */
 
 /* One linearised contact = the reference's Collision (collision_checker.hpp:19-29) + the AffExpr pieces of
@@ -100,7 +104,7 @@ int tohc_upload_scene(tohc_engine *e, int n_shapes, const int32_t *shape_kind, c
 
 /* replaces RobotAndDOF (configuration_space.hpp) + OpenRAVE's FK / CalculateActiveJacobian  configuration_space.cpp:12-23,83-133
  * Flattened joint tree, parents first; conventions in DESIGN.md ("FK model").  link_obj[i] = scene object carrying the
- * link's geometry (-1: none).  The optimisation vector is [q[joint_inds]..., affine X, Y, Z, RotationAxis]. */
+ * link's geometry (-1: none); grabbed bodies: see TOHC_DOF_GRABBED.  The optimisation vector is [q[joint_inds]..., affine X, Y, Z, RotationAxis]. */
 int tohc_upload_robot(tohc_engine *e, int n_links, const int32_t *parent, const int32_t *jtype, const double *T_origin /*[n][7]*/,
                       const double *axis /*[n][3]*/, const int32_t *dof, const double *mult, const double *offs,
                       const int32_t *link_obj, int n_dof, const double *q_robot, const double *base_T /*[7]*/,

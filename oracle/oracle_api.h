@@ -78,6 +78,10 @@ typedef struct ora_sweep_hit {
  * Transforms compose in fp64 quaternion form (q = qa*qb renormalised, t = qa.rotate(tb)+ta). */
 enum { ORA_J_FIXED = 0, ORA_J_REVOLUTE = 1, ORA_J_PRISMATIC = 2 };
 enum { ORA_DOF_X = 1, ORA_DOF_Y = 2, ORA_DOF_Z = 4, ORA_DOF_ROTAXIS = 8 };
+/* dof[i] of a FIXED link: marks the link of a body the robot has grabbed, hanging off its grabber link.
+ * RobotAndDOF::GetAffectedLinks lists such links unconditionally, with the grabber's index as their Jacobian link
+ * (configuration_space.cpp:120-131): they are queried even when no active DOF moves them. */
+#define ORA_DOF_GRABBED (-2)
 typedef struct ora_robot {
   int n_links;
   const int *parent;       /* [n_links]                                                       */

@@ -2018,6 +2018,7 @@ void ora_position_jacobian(const ora_robot *rb, const double *linkT7, const doub
 /* RobotAndDOF::DoesAffect [cs:97-101] + trajopt::DoesAffect (rave_utils.cpp:69-74) */
 int ora_link_affected(const ora_robot *rb, int link) {
   if (rb->affine > 0) return 1;
+  if (rb->dof[link] == ORA_DOF_GRABBED) return 1; /* a grabbed body's link: listed whatever moves it [cs:120-131] */
   for (int i = link; i >= 0; i = rb->parent[i]) {
     if (rb->jtype[i] == ORA_J_FIXED || rb->dof[i] < 0) continue;
     for (int a = 0; a < rb->n_joint_inds; ++a)

@@ -13,7 +13,8 @@
 #include <fstream>
 #include <sstream>
 
-#include "trajopt_host.hpp"
+#include "collision_terms_standin.hpp"
+#include "hip_collision_checker.hpp"
 
 using namespace OR;
 using namespace trajopt;
@@ -156,10 +157,15 @@ static void test_continuous_boxes() {
     checker->CastVsAll(*rad, boxbot->GetLinks(), DblVec(q0, q0 + 2), DblVec(q1, q1 + 2), a);
     checker->CastVsAll(*rad, links, DblVec(q0, q0 + 2), DblVec(q1, q1 + 2), b);
     EXPECT_EQ(a.size(), (size_t)1);
-    EXPECT_EQ(b.size(), (size_t)1);
-    if (a.size() == 1 && b.size() == 1) {
-      EXPECT_TRUE(a[0].distance == b[0].distance && a[0].time == b[0].time && a[0].normalB2A.x == b[0].normalB2A.x && a[0].normalB2A.y == b[0].normalB2A.y);
-      EXPECT_TRUE(b[0].grad0.empty());
+    // the box link as a (resting) cast query: its swept shape is a temporary object outside the world, so contactTest
+    // skips nothing and it meets its own object, which passes the KinBodyFilter mask -- the reference does the same
+    // (bullet_collision_checker.cpp:974-998, 886-892); robot links never do (RobotFilter is not in the mask)
+    EXPECT_EQ(b.size(), (size_t)2);
+    if (a.size() == 1 && b.size() == 2) {
+      const int k = (b[0].linkA == b[0].linkB) ? 1 : 0;
+      EXPECT_TRUE(a[0].distance == b[k].distance && a[0].time == b[k].time && a[0].normalB2A.x == b[k].normalB2A.x && a[0].normalB2A.y == b[k].normalB2A.y);
+      EXPECT_TRUE(b[k].grad0.empty());
+      EXPECT_TRUE(b[1 - k].linkA == box->GetLinks()[0].get() && b[1 - k].linkB == box->GetLinks()[0].get() && b[1 - k].distance < 0);
     }
   }
 }
@@ -188,6 +194,8 @@ struct World {
   RobotAndDOFPtr rad;
   TrajArray traj;
   double d, dist_pen, coeff;
+  struct Grab { KinBodyPtr body; int link; Transform rel; };
+  vector<Grab> grabs;
 };
 
 static void addGeoms(KinBody::Link& link, const Flat& F, int obj) {
@@ -200,6 +208,7 @@ static void addGeoms(KinBody::Link& link, const Flat& F, int obj) {
     switch ((int)kind[s]) {
       case TOHC_BOX: g.type = GT_Box, g.boxExtents = Vector(param[4 * s], param[4 * s + 1], param[4 * s + 2]); break;
       case TOHC_CYLZ: g.type = GT_Cylinder, g.radius = param[4 * s], g.height = 2 * param[4 * s + 1]; break;
+      case TOHC_SPHERE: g.type = GT_Sphere, g.radius = param[4 * s]; break;
       case TOHC_HULL:
         g.type = GT_TriMesh;
         for (int v = (int)voff[s]; v < (int)(voff[s] + vcnt[s]); ++v) g.meshVertices.push_back(Vector(verts[3 * v], verts[3 * v + 1], verts[3 * v + 2]));
@@ -227,8 +236,9 @@ static World loadWorld(const string& path) {
   const vector<double>&group = F.at("obj_group"), &staticT = F.at("static_T"), &linkObj = F.at("link_obj");
   int nObj = (int)group.size(), nLinks = (int)linkObj.size();
   vector<int> objLink(nObj, -1);
+  const vector<double>& dofOfLink = F.at("dof");
   for (int i = 0; i < nLinks; ++i)
-    if (linkObj[i] >= 0) objLink[(int)linkObj[i]] = i;
+    if (linkObj[i] >= 0 && (int)dofOfLink[i] != TOHC_DOF_GRABBED) objLink[(int)linkObj[i]] = i;   // a grabbed body's link: a KinBody of its own
   W.robot.reset(new RobotBase("robot"));
   bool robotAdded = false;
   for (int o = 0; o < nObj; ++o) {
@@ -244,7 +254,14 @@ static World loadWorld(const string& path) {
   }
   const vector<double>&parent = F.at("parent"), &jtype = F.at("jtype"), &origin = F.at("T_origin"), &axis = F.at("axis"), &dof = F.at("dof"),
                       &mult = F.at("mult"), &offs = F.at("offs");
-  for (int i = 0; i < nLinks; ++i) {
+  int nRobotLinks = nLinks;
+  for (int i = 0; i < nLinks; ++i)
+    if ((int)dof[i] == TOHC_DOF_GRABBED) { nRobotLinks = std::min(nRobotLinks, i); }
+  for (int i = nRobotLinks; i < nLinks; ++i) {   // model.RobotModel.grab(): robot->Grab(body, link) at the given relative pose
+    if ((int)dof[i] != TOHC_DOF_GRABBED) throw std::runtime_error("flat world: grabbed links come after the robot's own");
+    W.grabs.push_back(World::Grab{W.env->GetKinBody(oname((int)linkObj[i])), (int)parent[i], T7(origin, i)});
+  }
+  for (int i = 0; i < nRobotLinks; ++i) {
     RobotBase::Joint j;
     j.parent = (int)parent[i], j.type = (JointType)(int)jtype[i], j.origin = T7(origin, i), j.axis = Vector(axis[3 * i], axis[3 * i + 1], axis[3 * i + 2]);
     j.dof = (int)dof[i], j.mult = mult[i], j.offs = offs[i];
@@ -310,6 +327,7 @@ static void test_linearize(const string& in, const string& out) {
   HIPCollisionChecker* hip = dynamic_cast<HIPCollisionChecker*>(checker.get());
   EXPECT_TRUE(hip != NULL);
   checker->SetContactDistance((float)W.d);
+  for (const World::Grab& g : W.grabs) W.robot->GrabAt(g.body, W.robot->GetLinks()[g.link], g.rel);   // after the bodies were added, like a caller would
   int T = W.traj.rows(), K = W.traj.cols();
   DblVec x = W.traj.m_data;
 
@@ -333,7 +351,9 @@ static void test_linearize(const string& in, const string& out) {
   }
   // IgnoreZeroStateSelfCollisions() once more, now with a configuration bound (collision_checker.cpp:58-66): the robot is
   // lifted to z = 10 by SetTransform, which the bound DOF vector cannot express -- nothing may change
-  {
+  // (not with a grabbed body: it is carried along to z = 10, so the call -- rightly -- finds and excludes its contacts
+  // with the gripper that holds it)
+  if (W.grabs.empty()) {
     checker->IgnoreZeroStateSelfCollisions();
     Pass C = runCosts(W, x, false);
     EXPECT_EQ(A.values.size(), C.values.size());

@@ -1,7 +1,7 @@
 // rave_shim.hpp -- the handful of OpenRAVE types the collision path mentions, as plain C++.
 //
 // OpenRAVE (an un-vendored dependency of the reference, CMakeLists.txt:22-24) is not in this image, so the host
-// layer in trajopt_host.hpp cannot be compiled against it here.  This header declares stand-ins with the same names
+// layer (trajopt_amd/host/hip_collision_checker.hpp) cannot be compiled against it here.  This header declares stand-ins with the same names
 // and accessors that src/trajopt/{collision_checker.hpp, bullet_collision_checker.cpp, configuration_space.cpp,
 // collision_terms.cpp} use (KinBody, KinBody::Link, Link::Geometry, RobotBase, EnvironmentBase, Vector, Transform),
 // so that host code and its tests read like the reference's.  Inside a real OpenRAVE process this header is replaced
@@ -39,6 +39,13 @@ struct Transform {
     return Vector(v.x + w * tx + (b * tz - c * ty), v.y + w * ty + (c * tx - a * tz), v.z + w * tz + (a * ty - b * tx));
   }
   Vector operator*(const Vector& v) const { return rotate(v) + trans; }
+  Transform inverse() const {
+    Transform r;
+    r.rot = Vector(rot.x, -rot.y, -rot.z, -rot.w);
+    const Vector t = r.rotate(trans);
+    r.trans = Vector(-t.x, -t.y, -t.z);
+    return r;
+  }
   bool isIdentity() const { return rot.x == 1 && rot.y == 0 && rot.z == 0 && rot.w == 0 && trans.x == 0 && trans.y == 0 && trans.z == 0; }
   Transform operator*(const Transform& o) const {
     if (o.isIdentity()) return *this;   // keep poses bit-exact through the common single-link case
@@ -147,6 +154,40 @@ class RobotBase : public KinBody {
   void CacheAffineDOFValues(int affinedofs, const Vector& axis, const std::vector<double>& vals) {
     m_affCacheDofs = affinedofs, m_affCacheAxis = axis, m_affCacheVals = vals, m_affCacheStamp = m_stamp;
   }
+  // Grab / Release / GetGrabbed / IsGrabbing as OpenRAVE has them (configuration_space.cpp:120-131 uses the last two).
+  // The grabbed body keeps its pose relative to the grabbing link: `rel` = link^-1 * body at the time of the grab (the
+  // link's pose must be current then: HIPCollisionChecker::UpdateRobotLinkTransforms); GetGrabbedInfo is the shim's
+  // window on it (OpenRAVE: RobotBase::GetGrabbedInfo, _trelative).
+  struct Grabbed { std::shared_ptr<KinBody> body; int link; Transform rel; };
+  void Grab(std::shared_ptr<KinBody> body, LinkPtr link) {
+    Release(body);
+    Grabbed g;
+    g.body = body, g.link = link->GetIndex(), g.rel = link->GetTransform().inverse() * body->GetTransform();
+    m_grabbed.push_back(g);
+    ++m_stamp;
+  }
+  // the same with the relative pose given (OpenRAVE: ResetGrabbed with a GrabbedInfo::_trelative)
+  void GrabAt(std::shared_ptr<KinBody> body, LinkPtr link, const Transform& rel) {
+    Release(body);
+    Grabbed g;
+    g.body = body, g.link = link->GetIndex(), g.rel = rel;
+    m_grabbed.push_back(g);
+    ++m_stamp;
+  }
+  void Release(std::shared_ptr<KinBody> body) {
+    for (size_t i = 0; i < m_grabbed.size(); ++i)
+      if (m_grabbed[i].body == body) { m_grabbed.erase(m_grabbed.begin() + i); ++m_stamp; return; }
+  }
+  void GetGrabbed(std::vector<std::shared_ptr<KinBody> >& out) const {
+    out.clear();
+    for (const Grabbed& g : m_grabbed) out.push_back(g.body);
+  }
+  LinkPtr IsGrabbing(const std::shared_ptr<KinBody>& body) const {
+    for (const Grabbed& g : m_grabbed)
+      if (g.body == body) return m_links[g.link];
+    return LinkPtr();
+  }
+  const std::vector<Grabbed>& GetGrabbedInfo() const { return m_grabbed; }
   bool GetCachedAffineDOFValues(int affinedofs, const Vector& axis, std::vector<double>& vals) const {
     if (m_affCacheStamp != m_stamp || m_affCacheDofs != affinedofs || m_affCacheAxis.x != axis.x || m_affCacheAxis.y != axis.y || m_affCacheAxis.z != axis.z)
       return false;
@@ -156,6 +197,7 @@ class RobotBase : public KinBody {
 
  private:
   std::vector<Joint> m_joints;
+  std::vector<Grabbed> m_grabbed;
   std::vector<double> m_dofvalues;
   unsigned long m_stamp = 0, m_affCacheStamp = ~0ul;
   int m_affCacheDofs = 0;

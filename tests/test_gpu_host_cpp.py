@@ -44,6 +44,23 @@ def _world(cfg):
         q0 = rb.q_robot[1:8] + rng.uniform(-0.5, 0.5, size=7)
         traj = synth.straight_line(q0, q0 + rng.uniform(-0.9, 0.9, size=7), 10)
         return s, rb, static_T, 0.065, traj, 0.025
+    if cfg == "arm_grab_spheres":   # the arm holding a box (robot->Grab, configuration_space.cpp:120-131) among spheres and a cylinder
+        s = M.Scene()
+        rb = synth.pr2_like(s, seed=0, active="rightarm")
+        rng = np.random.default_rng(12)
+        held = s.add_object([(s.add_box(0.03, 0.03, 0.12), M.IDENT7)], M.GROUP_KINBODY, name="held")
+        ids, Ts = [], []
+        for i in range(6):
+            ids.append(s.add_object([(s.add_sphere(rng.uniform(0.05, 0.15)), M.IDENT7)], M.GROUP_KINBODY))
+            Ts.append(synth.T7(rng.uniform([0.3, -0.8, 0.4], [0.9, 0.2, 1.2])))
+        ids.append(s.add_object([(s.add_cylinder(0.06, 0.3), M.IDENT7)], M.GROUP_KINBODY))
+        Ts.append(synth.T7((0.6, -0.4, 0.7)))
+        rb.grab(rb.link_name.index("r_gripper_palm_link"), synth.T7((0.12, 0, 0), (0, 1, 0), 0.3), held)
+        s.finalize(); rb.finalize()
+        static_T = synth.static_poses(s, ids, np.array(Ts))
+        q0 = rb.q_robot[1:8] + rng.uniform(-0.5, 0.5, size=7)
+        traj = synth.straight_line(q0, q0 + rng.uniform(-0.9, 0.9, size=7), 8)
+        return s, rb, static_T, 0.09, traj, 0.05
     s, rb, static_T, d = synth.config_fullbody_soup(n_hulls=256)    # configs[3] with a smaller soup, 12 timesteps
     traj = synth.fullbody_trajectory(rb, np.random.default_rng(1000), 12)
     return s, rb, static_T, d, traj, 0.05
@@ -52,7 +69,7 @@ def _world(cfg):
 KEY = ("t", "idA", "childA", "idB", "childB")
 
 
-@pytest.mark.parametrize("cfg", ["arm_table", "fullbody_soup256"])
+@pytest.mark.parametrize("cfg", ["arm_table", "fullbody_soup256", "arm_grab_spheres"])
 def test_cpp_collision_terms_vs_python_host_and_oracle(built, tmp_path, cfg):
     s, rb, static_T, d, traj, dist_pen = _world(cfg)
     coeff = 20.0

@@ -288,6 +288,52 @@ def test_robot_vs_spheres_and_cylinders(eng):
     w.close()
 
 
+def test_grabbed_bodies(eng):
+    """robot->Grab(body, link) (configuration_space.cpp:120-131): the grabbed body's links are query links with the
+    GRABBER's Jacobian, whether or not an active DOF moves the grabber -- here a box in the right gripper (moved by the
+    active right arm) and a hull in the left gripper (left arm inactive: listed all the same, gradient rows all zero)."""
+    s = M.Scene()
+    rb = synth.pr2_like(s, seed=0, active="rightarm")
+    rng = np.random.default_rng(33)
+    held_r = s.add_object([(s.add_box(0.03, 0.03, 0.12), M.IDENT7)], M.GROUP_KINBODY, name="held_r")
+    held_l = s.add_object([(s.add_hull(synth.blob_hull(rng, scale=(0.05, 0.05, 0.05), nverts=20)), synth.T7((0.02, 0, 0))),
+                           (s.add_sphere(0.04), synth.T7((0, 0, 0.08)))], M.GROUP_KINBODY, compound=True, name="held_l")
+    gr = rb.grab(rb.link_name.index("r_gripper_palm_link"), synth.T7((0.12, 0, 0), (0, 1, 0), 0.3), held_r)
+    gl = rb.grab(rb.link_name.index("l_gripper_palm_link"), synth.T7((0.12, 0, 0)), held_l)
+    ids, boxT = synth.add_boxes(s, TABLE + [((.2, .3, .4), synth.T7((0.6, -0.6, 0.4), (0, 0, 1), 0.5)), ((.1, .1, .02), M.IDENT7), ((.1, .1, .02), M.IDENT7)])
+    s.finalize(); rb.finalize()
+    static_T = synth.static_poses(s, ids, boxT)
+    objs, links = rb.affected_links()
+    assert held_r in objs and held_l in objs and links[objs.index(held_l)] == gl
+    B_, T_ = 2, 8
+    dofs = np.stack([synth.straight_line(rb.q_robot[1:8] + rng.uniform(-0.5, 0.5, 7), rb.q_robot[1:8] + rng.uniform(-1.0, 1.0, 7), T_) for _ in range(B_)])
+    # the last two boxes sit next to where the held objects are (FK of the build's own model)
+    fk = B.oracle_fk(rb, dofs[0, T_ // 2])
+    static_T[ids[-2], 4:] = fk[gr, 4:] + [0.0, 0.0, -0.1]
+    static_T[ids[-1], 4:] = fk[gl, 4:] + [0.05, 0.0, -0.1]
+    eng.upload_scene(s, static_T)
+    eng.upload_robot(rb)
+    eng.set_contact_distance(0.09)
+    w = B.oracle_world(s)
+    w.set_contact_distance(0.09)
+    seen_r = seen_l = 0
+    for cast in (False, True):
+        rec, g = eng.cast_vs_all_batch(dofs, B_, T_, 1) if cast else eng.links_vs_all_batch(dofs, B_, T_)
+        for b in range(B_):
+            orec, og = w.linearize(rb, static_T, dofs[b], cast=cast)
+            sel = rec["problem"] == b
+            util.assert_same_linearization(rec[sel], g[sel], orec, og, "grabbed cast=%s b=%d" % (cast, b))
+        # the held objects as the query side (B after the cast swap; either side in the discrete pass)
+        env = np.isin(rec["idA"], ids) | np.isin(rec["idB"], ids)
+        mr = env & ((rec["idA"] == held_r) | (rec["idB"] == held_r))
+        ml = env & ((rec["idA"] == held_l) | (rec["idB"] == held_l))
+        seen_r += int(mr.sum()); seen_l += int(ml.sum())
+        assert np.abs(g[mr]).max(initial=0) > 0 or not mr.any()
+        assert not g[ml].any()            # nothing active moves the left gripper: d dist / d q = 0, the contact is still reported
+    assert seen_r > 0 and seen_l > 0
+    w.close()
+
+
 def test_allowed_matrix_and_group64_agree(eng):
     s, rb, static_T = _arm_world("rightarm", TABLE)
     eng.upload_scene(s, static_T)

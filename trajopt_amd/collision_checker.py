@@ -116,10 +116,12 @@ class HIPCollisionChecker:
         # BodyVsAll: EVERY link of the body is a query, not only those a joint moves (collision_checker.cpp:49)
         T = self.static_T.copy()
         fk = self.eng.forward_kinematics(np.zeros((1, zero.K)))[0]
-        body = [o for o in rb.link_obj if o >= 0]
-        for i, o in enumerate(rb.link_obj):
-            if o >= 0:
-                T[o] = fk[i]
+        # (a grabbed body is not part of the robot's KinBody: it is neither lifted nor a query here -- the reference runs
+        # this when a body is ADDED, bullet_collision_checker.cpp:636-641, before anything can be grabbed)
+        own = [i for i, o in enumerate(rb.link_obj) if o >= 0 and rb.dof[i] != M.DOF_GRABBED]
+        body = [rb.link_obj[i] for i in own]
+        for i in own:
+            T[rb.link_obj[i]] = fk[i]
         rec = self.eng.links_vs_all_poses(T, body, -1)
         for a, b in zip(rec["idA"].tolist(), rec["idB"].tolist()):
             self.allowed[a, b] = self.allowed[b, a] = 0

@@ -606,6 +606,8 @@ int tohc_upload_robot(tohc_engine *e, int n_links, const int32_t *parent, const 
     for (int i = 0; i < n_links; ++i) {
       if (parent[i] >= i || parent[i] < -1) return fail(e, TOHC_E_INVALID, "upload_robot: link %d: parents must precede children", i);
       if (dof[i] >= n_dof) return fail(e, TOHC_E_INVALID, "upload_robot: link %d: dof %d out of range", i, dof[i]);
+      if (dof[i] == TOHC_DOF_GRABBED && (jtype[i] != TOHC_J_FIXED || parent[i] < 0))
+        return fail(e, TOHC_E_INVALID, "upload_robot: link %d: a grabbed body's link is a fixed link with a grabber (parent)", i);
       if (jtype[i] != TOHC_J_FIXED && jtype[i] != TOHC_J_REVOLUTE && jtype[i] != TOHC_J_PRISMATIC)
         return fail(e, TOHC_E_INVALID, "upload_robot: link %d: unknown joint type %d", i, jtype[i]);
       if (link_obj[i] >= e->n_objects) return fail(e, TOHC_E_INVALID, "upload_robot: link %d: object %d out of range", i, link_obj[i]);
@@ -641,7 +643,7 @@ int tohc_upload_robot(tohc_engine *e, int n_links, const int32_t *parent, const 
     int o = link_obj[i];
     if (o < 0) continue;
     e->h_obj_dynR[o] = nd; e->h_link_dyn[i] = nd; ++nd;
-    bool affected = affine > 0;
+    bool affected = affine > 0 || dof[i] == TOHC_DOF_GRABBED;   // GetAffectedLinks lists grabbed links unconditionally (:120-131)
     for (int j = i; j >= 0 && !affected; j = parent[j])
       if (e->h_dof_col[j] >= 0) affected = true;
     for (int k = 0; k < e->h_obj_cnt[o]; ++k) {
@@ -862,7 +864,7 @@ static int64_t countAabbTests(const tohc_engine *e, const std::vector<int> &qchi
   for (int q : qchildren) {
     int Q = e->h_child_obj[q];
     for (int X = 0; X < e->n_objects; ++X) {
-      if (X == Q) continue;
+      if (X == Q && !cp.cast) continue;   // (the swept temporary object is not in the world: no self to skip)
       int g = e->h_obj_group[X];
       if (cp.cast ? !(g & TOHC_GROUP_KINBODY) : !(g & (short)cp.filter_mask)) continue;
       if (!e->h_allowed[(size_t)Q * e->n_objects + X]) continue;

@@ -467,8 +467,10 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
           c = mk(sx.c[0], sx.c[1], sx.c[2]);
           rad = sx.r;
         }
-        keep = (X != Q) && (CAST ? (gx & TOHC_GROUP_KINBODY) != 0 : (gx & (short)cp.filter_mask) != 0)  // cast: KinBodyFilter (bcc:983)
-               && allowedRow[X] != 0;
+        // discrete: contactTest skips the query object itself (btCollisionWorld.cpp:1132-1133).  Cast: the swept shape is a
+        // temporary object that is not in the world, so nothing is skipped -- a query link whose own object passes the
+        // KinBodyFilter mask (a grabbed body's link) meets its resting self, as in the reference (bcc:983, 886-892)
+        keep = (CAST || X != Q) && (CAST ? (gx & TOHC_GROUP_KINBODY) != 0 : (gx & (short)cp.filter_mask) != 0) && allowedRow[X] != 0;
       }
       ncand += (unsigned int)__popcll(__ballot(keep));
       if (ca.dbg == 1) keep = false;

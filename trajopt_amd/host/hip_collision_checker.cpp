@@ -1,9 +1,10 @@
-// trajopt_host.cpp -- see trajopt_host.hpp.  Every device operation goes through the C-ABI of libtrajopt_hipcc.so;
-// there is no CPU path here: without the library / a GPU, tohc_create fails and the constructor throws.
-#include "trajopt_host.hpp"
+// hip_collision_checker.cpp -- see hip_collision_checker.hpp.  Every device operation goes through the C-ABI of
+// libtrajopt_hipcc.so; there is no CPU path here: without the library / a GPU, tohc_create fails and the constructor throws.
+#include "hip_collision_checker.hpp"
 
 #include <algorithm>
 #include <cassert>
+#include <cstdlib>
 #include <functional>
 
 namespace trajopt {
@@ -24,113 +25,18 @@ static bool isIdentity(const Transform& T) {   // bullet_collision_checker.cpp:8
   return fabs(T.trans.x) < e && fabs(T.trans.y) < e && fabs(T.trans.z) < e && fabs(T.rot.x - 1) < e && fabs(T.rot.y) < e && fabs(T.rot.z) < e &&
          fabs(T.rot.w) < e;
 }
-static size_t hashRange(const DblVec& x, size_t seed = 0) {   // boost::hash_range (collision_terms.cpp:82-84)
-  std::hash<double> h;
-  for (double v : x) seed ^= h(v) + 0x9e3779b9 + (seed << 6) + (seed >> 2);
-  return seed;
-}
-static int affineCount(int a) { return ((a & 1) != 0) + ((a & 2) != 0) + ((a & 4) != 0) + ((a & 8) != 0); }
 
-std::ostream& operator<<(std::ostream& o, const Collision& c) {   // collision_checker.cpp:68-77
-  auto v = [&](const Vector& a) { o << "[" << a.x << ", " << a.y << ", " << a.z << "]"; };
-  o << (c.linkA ? c.linkA->GetName() : "NULL") << "--" << (c.linkB ? c.linkB->GetName() : "NULL") << " distance: " << c.distance << " normal: ";
-  v(c.normalB2A); o << " ptA: "; v(c.ptA); o << " ptB: "; v(c.ptB);
-  o << " time: " << c.time << " weight: " << c.weight;
-  return o;
-}
-
-// ===================================================================================================================
-// CollisionChecker (collision_checker.cpp)
-// ===================================================================================================================
-std::shared_ptr<CollisionChecker> CollisionChecker::GetOrCreate(OR::EnvironmentBase& env) {   // :16-27
-  OR::UserDataPtr ud = env.m_userdata["trajopt_cc"];
-  if (!ud) {
-    ud = CreateCollisionChecker(env.shared_from_this());
-    env.m_userdata["trajopt_cc"] = ud;
-  }
-  return std::dynamic_pointer_cast<CollisionChecker>(ud);
-}
-
-void CollisionChecker::IgnoreZeroStateSelfCollisions(OR::KinBodyPtr body) {   // :41-56
-  // KinBodyStateSaver
-  Transform savedT = body->GetTransform();
-  RobotBase* rb = dynamic_cast<RobotBase*>(body.get());
-  DblVec savedQ;
-  if (rb) savedQ = rb->GetDOFValues(), rb->SetDOFValues(DblVec(rb->GetDOF(), 0.0));
-  body->SetTransform(Transform(Vector(1, 0, 0, 0), Vector(0, 0, 10)));
-  vector<Collision> collisions;
-  BodyVsAll(*body, collisions);
-  for (size_t i = 0; i < collisions.size(); ++i) ExcludeCollisionPair(*collisions[i].linkA, *collisions[i].linkB);
-  if (rb) rb->SetDOFValues(savedQ);
-  body->SetTransform(savedT);
-}
-
-void CollisionChecker::IgnoreZeroStateSelfCollisions() {   // :58-66
-  vector<OR::KinBodyPtr> bodies;
-  GetEnv()->GetBodies(bodies);
-  for (auto& b : bodies) IgnoreZeroStateSelfCollisions(b);
-}
-
-CollisionCheckerPtr CreateCollisionChecker(OR::EnvironmentBaseConstPtr env) {   // bullet_collision_checker.cpp:1036-1039
+// The one factory of the reference (collision_checker.hpp:87, body at bullet_collision_checker.cpp:1036-1039), with the
+// switch SURVEY.md 5 asks for: TRAJOPT_COLLISION_CHECKER = hip (default) | bullet.  Upstream the second branch is the
+// reference's own `new BulletCollisionChecker(env)`; that class needs OpenRAVE + the vendored Bullet and is not part of
+// this build, so asking for it here is an error, never a silent substitute.
+CollisionCheckerPtr CreateCollisionChecker(OR::EnvironmentBaseConstPtr env) {
+  const char* which = getenv("TRAJOPT_COLLISION_CHECKER");
+  if (which && std::string(which) == "bullet")
+    throw std::runtime_error("TRAJOPT_COLLISION_CHECKER=bullet: the reference's BulletCollisionChecker is not part of this build");
+  if (which && std::string(which) != "hip" && std::string(which) != "")
+    throw std::runtime_error(std::string("TRAJOPT_COLLISION_CHECKER: unknown checker '") + which + "' (hip | bullet)");
   return CollisionCheckerPtr(new HIPCollisionChecker(env));
-}
-
-// ===================================================================================================================
-// RobotAndDOF (configuration_space.cpp)
-// ===================================================================================================================
-int RobotAndDOF::GetDOF() const { return (int)joint_inds.size() + affineCount(affinedofs); }   // :80-82
-
-void RobotAndDOF::SetDOFValues(const DblVec& dofs) {   // :12-23
-  if ((int)dofs.size() != GetDOF()) throw std::runtime_error("RobotAndDOF::SetDOFValues: wrong number of values");
-  if (affinedofs != 0) {
-    // RaveGetTransformFromAffineDOFValues on a default (identity) transform: X, Y, Z, then the angle about rotationaxis
-    Transform T;
-    size_t i = joint_inds.size();
-    if (affinedofs & OR::DOF_X) T.trans.x = dofs[i++];
-    if (affinedofs & OR::DOF_Y) T.trans.y = dofs[i++];
-    if (affinedofs & OR::DOF_Z) T.trans.z = dofs[i++];
-    if (affinedofs & OR::DOF_RotationAxis) {
-      double a = dofs[i++], s = sin(a / 2);
-      T.rot = Vector(cos(a / 2), rotationaxis.x * s, rotationaxis.y * s, rotationaxis.z * s);
-    }
-    robot->SetTransform(T);
-    if (joint_inds.size() > 0) robot->SetDOFValues(DblVec(dofs.begin(), dofs.begin() + joint_inds.size()), joint_inds);
-  } else {
-    robot->SetDOFValues(dofs, joint_inds);
-  }
-  robot->CacheAffineDOFValues(affinedofs, rotationaxis, DblVec(dofs.begin() + joint_inds.size(), dofs.end()));
-}
-
-DblVec RobotAndDOF::GetDOFValues() {   // :25-35
-  DblVec out, aff;
-  for (int j : joint_inds) out.push_back(robot->GetDOFValues().at(j));
-  if (affinedofs != 0 && robot->GetCachedAffineDOFValues(affinedofs, rotationaxis, aff)) {
-    out.insert(out.end(), aff.begin(), aff.end());
-  } else if (affinedofs != 0) {   // RaveGetAffineDOFValuesFromTransform
-    const Transform& T = robot->GetTransform();
-    if (affinedofs & OR::DOF_X) out.push_back(T.trans.x);
-    if (affinedofs & OR::DOF_Y) out.push_back(T.trans.y);
-    if (affinedofs & OR::DOF_Z) out.push_back(T.trans.z);
-    if (affinedofs & OR::DOF_RotationAxis)
-      out.push_back(2 * atan2(T.rot.y * rotationaxis.x + T.rot.z * rotationaxis.y + T.rot.w * rotationaxis.z, T.rot.x));
-  }
-  return out;
-}
-
-bool RobotAndDOF::DoesAffect(const KinBody::Link& link) {   // :97-101, rave_utils.cpp:69-74
-  if (affinedofs > 0) return true;
-  if (link.GetParent() != robot.get()) return false;
-  const vector<RobotBase::Joint>& J = robot->GetJoints();
-  for (int i = link.GetIndex(); i >= 0; i = J[i].parent)
-    if (J[i].type != OR::JointFixed && std::find(joint_inds.begin(), joint_inds.end(), J[i].dof) != joint_inds.end()) return true;
-  return false;
-}
-
-void RobotAndDOF::GetAffectedLinks(vector<KinBody::LinkPtr>& links, bool only_with_geom, vector<int>& link_inds) {   // :110-118
-  links.clear(), link_inds.clear();
-  for (const KinBody::LinkPtr& link : robot->GetLinks())
-    if (DoesAffect(*link) && !(only_with_geom && link->GetGeometries().empty())) links.push_back(link), link_inds.push_back(link->GetIndex());
-  // grabbed bodies (:120-131): the shim has no Grab(); SURVEY.md 8(f3)
 }
 
 // ===================================================================================================================
@@ -243,8 +149,12 @@ void HIPCollisionChecker::UpdateFromRave() {   // UpdateBulletFromRave, :629-655
   }
   // Queries on explicit link lists hand the engine every pose (CurrentPoses).  The linearizing queries run FK on the
   // device and take the poses of everything that is not a robot link from the scene upload: refresh it when one moved.
+  std::set<const KinBody*> carried;   // grabbed bodies move with their robot: their poses come from FK, not from the upload
+  for (const OR::KinBodyPtr& b : bodies)
+    if (const RobotBase* rb = dynamic_cast<const RobotBase*>(b.get()))
+      for (const RobotBase::Grabbed& g : rb->GetGrabbedInfo()) carried.insert(g.body.get());
   for (size_t o = 0; o < m_obj2link.size(); ++o) {
-    if (m_obj2link[o]->GetParent()->IsRobot()) continue;
+    if (m_obj2link[o]->GetParent()->IsRobot() || carried.count(m_obj2link[o]->GetParent())) continue;
     double t7[7];
     put7(m_obj2link[o]->GetTransform(), t7);
     if (memcmp(t7, &m_uploadedT[7 * o], sizeof t7)) {
@@ -286,6 +196,7 @@ bool HIPCollisionChecker::RobotUploadIsCurrent(RobotAndDOF& rad) const {
   if ((rad.affinedofs & OR::DOF_RotationAxis) &&
       (m_upRotAxis.x != rad.rotationaxis.x || m_upRotAxis.y != rad.rotationaxis.y || m_upRotAxis.z != rad.rotationaxis.z))
     return false;
+  if (GrabSignature(*r) != m_upGrab) return false;
   const DblVec& q = r->GetDOFValues();
   for (size_t j = 0; j < q.size(); ++j)   // the joints that are not optimised keep the values of the upload
     if (q[j] != m_upQ[j] && std::find(rad.joint_inds.begin(), rad.joint_inds.end(), (int)j) == rad.joint_inds.end()) return false;
@@ -297,14 +208,41 @@ bool HIPCollisionChecker::RobotUploadIsCurrent(RobotAndDOF& rad) const {
   return true;
 }
 
+// what of the robot's grabbed bodies the upload depends on: (body, grabbing link, relative pose) of each
+vector<double> HIPCollisionChecker::GrabSignature(const RobotBase& r) const {
+  vector<double> sig;
+  for (const RobotBase::Grabbed& g : r.GetGrabbedInfo()) {
+    double t7[7];
+    put7(g.rel, t7);
+    sig.push_back((double)(uintptr_t)g.body.get()), sig.push_back(g.link);
+    sig.insert(sig.end(), t7, t7 + 7);
+  }
+  return sig;
+}
+
 void HIPCollisionChecker::UploadRobot(RobotAndDOF& rad) {
   if (RobotUploadIsCurrent(rad)) return;
   RobotBase* r = rad.robot.get();
   const vector<RobotBase::Joint>& J = r->GetJoints();
-  int n = (int)J.size();
+  const int nr = (int)J.size();
+  // Grabbed bodies (configuration_space.cpp:120-131): every link with geometry of a grabbed body becomes a FIXED link
+  // hanging off the grabbing link, marked TOHC_DOF_GRABBED -- a query link whatever moves it, with the grabber's Jacobian
+  struct Extra { int parent; Transform origin; const KinBody::Link* link; };
+  vector<Extra> extra;
+  for (const RobotBase::Grabbed& g : r->GetGrabbedInfo())
+    for (const KinBody::LinkPtr& l : g.body->GetLinks())
+      if (!l->GetGeometries().empty() && m_link2obj.count(l.get())) extra.push_back(Extra{g.link, g.rel * l->m_rel, l.get()});
+  int n = nr + (int)extra.size();
   vector<int32_t> parent(n), jtype(n), dof(n), linkObj(n);
   vector<double> origin(7 * n), axis(3 * n), mult(n), offs(n);
-  for (int i = 0; i < n; ++i) {
+  for (int k = 0; k < (int)extra.size(); ++k) {
+    const int i = nr + k;
+    parent[i] = extra[k].parent, jtype[i] = TOHC_J_FIXED, dof[i] = TOHC_DOF_GRABBED, mult[i] = 1, offs[i] = 0;
+    put7(extra[k].origin, &origin[7 * i]);
+    axis[3 * i] = 0, axis[3 * i + 1] = 0, axis[3 * i + 2] = 1;
+    linkObj[i] = m_link2obj.at(extra[k].link);
+  }
+  for (int i = 0; i < nr; ++i) {
     parent[i] = J[i].parent, jtype[i] = J[i].type, dof[i] = J[i].dof, mult[i] = J[i].mult, offs[i] = J[i].offs;
     put7(J[i].origin, &origin[7 * i]);
     double l = sqrt(J[i].axis.x * J[i].axis.x + J[i].axis.y * J[i].axis.y + J[i].axis.z * J[i].axis.z);
@@ -320,6 +258,7 @@ void HIPCollisionChecker::UploadRobot(RobotAndDOF& rad) {
   chk(tohc_upload_robot(m_e, n, parent.data(), jtype.data(), origin.data(), axis.data(), dof.data(), mult.data(), offs.data(), linkObj.data(),
                         (int)q.size(), q.empty() ? &qdummy : q.data(), base, (int)ji.size(), ji.data(), rad.affinedofs, rot));
   m_upRobot = r, m_upJointInds = rad.joint_inds, m_upAffine = rad.affinedofs, m_upRotAxis = rad.rotationaxis, m_upQ = q, m_upBase = r->GetTransform();
+  m_upGrab = GrabSignature(*r), m_upLinks = n;
 }
 
 void HIPCollisionChecker::BindConfiguration(Configuration& c) {
@@ -360,6 +299,7 @@ void HIPCollisionChecker::UpdateRobotLinkTransforms() {
     if (r->GetDOF() == 0) {   // a rigid robot (boxbot): compose on the host, nothing for the FK kernel to do
       for (size_t i = 0; i < J.size(); ++i)
         r->GetLinks()[i]->m_T = (J[i].parent < 0 ? r->GetTransform() : r->GetLinks()[J[i].parent]->m_T) * J[i].origin;
+      for (const RobotBase::Grabbed& g : r->GetGrabbedInfo()) g.body->SetTransform(r->GetLinks()[g.link]->m_T * g.rel);
       continue;
     }
     if (m_fkRobot == r && m_fkStamp == r->GetStamp()) continue;
@@ -368,10 +308,12 @@ void HIPCollisionChecker::UpdateRobotLinkTransforms() {
     for (int j = 0; j < r->GetDOF(); ++j) all[j] = j;
     RobotAndDOF full(std::dynamic_pointer_cast<RobotBase>(body), all, 0);
     UploadRobot(full);
-    vector<double> linkT(7 * J.size());
+    vector<double> linkT(7 * (size_t)m_upLinks);   // the robot's links, then the grabbed bodies' (UploadRobot)
     chk(tohc_forward_kinematics(m_e, r->GetDOFValues().data(), 1, linkT.data()));
     ++m_engineCalls;
     for (size_t i = 0; i < J.size(); ++i) r->GetLinks()[i]->m_T = get7(&linkT[7 * i]);
+    for (const RobotBase::Grabbed& g : r->GetGrabbedInfo())   // OpenRAVE carries grabbed bodies along with the grabbing link
+      g.body->SetTransform(r->GetLinks()[g.link]->m_T * g.rel);
     m_fkRobot = r, m_fkStamp = r->GetStamp();
   }
 }
@@ -591,170 +533,6 @@ void HIPCollisionChecker::PrefetchTrajectory(Configuration& rad, const TrajArray
     m_prefetch[(isCast ? nd : 0) + r[i].t].collisions.push_back(ToCollision(r[i], g + (size_t)i * 2 * K, K));
   }
   for (int i = 0; i < nd + nc; ++i) m_prefetchIndex.insert(std::make_pair(hashRange(m_prefetch[i].q0, m_prefetch[i].q1.empty() ? 0 : 1), i));
-}
-
-// ===================================================================================================================
-// collision_terms.cpp
-// ===================================================================================================================
-void CollisionsToDistances(const vector<Collision>& collisions, const Link2Int& link2ind, DblVec& dists) {   // :22-35
-  dists.clear();
-  dists.reserve(collisions.size());
-  for (const Collision& col : collisions)
-    if (link2ind.find(col.linkA) != link2ind.end() || link2ind.find(col.linkB) != link2ind.end()) dists.push_back(col.distance);
-}
-
-// :37-62.  The reference computes, per robot-side link, dist_grad = +-n^T J(link, pt) through PositionJacobian and adds
-// varDot(dist_grad, vars) - dist_grad . dofvals.  The kernels did exactly that sum over both sides in k_finish:
-// grad = sum of the sides' rows, const = distance - grad . dofvals.  So the expression is assembled, not recomputed.
-void CollisionsToDistanceExpressions(const vector<Collision>& collisions, Configuration&, const Link2Int& link2ind, const VarVector& vars,
-                                     const DblVec&, vector<AffExpr>& exprs, bool isTimestep1) {
-  exprs.clear();
-  exprs.reserve(collisions.size());
-  for (const Collision& col : collisions) {
-    if (link2ind.find(col.linkA) == link2ind.end() && link2ind.find(col.linkB) == link2ind.end()) continue;
-    const DblVec& g = isTimestep1 ? col.grad1 : col.grad0;
-    if (g.size() != vars.size())
-      throw std::runtime_error("CollisionsToDistanceExpressions: this contact carries no linearization (it came from a query on an explicit "
-                               "link list; PositionJacobian needs OpenRAVE)");
-    AffExpr dist(isTimestep1 ? col.const1 : col.const0);
-    exprInc(dist, varDot(g, vars));
-    exprs.push_back(dist);
-  }
-}
-
-void CollisionsToDistanceExpressions(const vector<Collision>& collisions, Configuration& rad, const Link2Int& link2ind, const VarVector& vars0,
-                                     const VarVector& vars1, const DblVec& vals0, const DblVec& vals1, vector<AffExpr>& exprs) {   // :64-80
-  vector<AffExpr> exprs0, exprs1;
-  CollisionsToDistanceExpressions(collisions, rad, link2ind, vars0, vals0, exprs0, false);
-  CollisionsToDistanceExpressions(collisions, rad, link2ind, vars1, vals1, exprs1, true);
-  exprs.resize(exprs0.size());
-  for (size_t i = 0; i < exprs0.size(); ++i) {
-    exprScale(exprs0[i], (1 - collisions[i].time));
-    exprScale(exprs1[i], collisions[i].time);
-    exprs[i] = AffExpr(0);
-    exprInc(exprs[i], exprs0[i]);
-    exprInc(exprs[i], exprs1[i]);
-    // cleanupAff's result is discarded in the reference (:78): tiny coefficients are kept
-  }
-}
-
-void CollisionEvaluator::GetCollisionsCached(const DblVec& x, vector<Collision>& collisions) {   // :86-98
-  size_t key = hashRange(getDblVec(x, GetVars()));
-  vector<Collision>* it = m_cache.get(key);
-  if (it != NULL) {
-    collisions = *it;
-  } else {
-    CalcCollisions(x, collisions);
-    m_cache.put(key, collisions);
-  }
-}
-
-static void bind(CollisionCheckerPtr cc, Configuration& rad) {
-  // the one line the reference's evaluators do not have: tell the checker which configuration LinksVsAll linearizes
-  if (HIPCollisionChecker* h = dynamic_cast<HIPCollisionChecker*>(cc.get())) h->BindConfiguration(rad);
-}
-
-SingleTimestepCollisionEvaluator::SingleTimestepCollisionEvaluator(ConfigurationPtr rad, const VarVector& vars)   // :100-115
-    : m_env(rad->GetEnv()), m_cc(CollisionChecker::GetOrCreate(*m_env)), m_rad(rad), m_vars(vars), m_filterMask(-1) {
-  vector<int> inds;
-  rad->GetAffectedLinks(m_links, true, inds);
-  for (size_t i = 0; i < m_links.size(); ++i) m_link2ind[m_links[i].get()] = inds[i];
-}
-
-void SingleTimestepCollisionEvaluator::CalcCollisions(const DblVec& x, vector<Collision>& collisions) {   // :118-122
-  DblVec dofvals = getDblVec(x, m_vars);
-  bind(m_cc, *m_rad);
-  m_rad->SetDOFValues(dofvals);
-  m_cc->LinksVsAll(m_links, collisions, m_filterMask);
-}
-
-void SingleTimestepCollisionEvaluator::CalcDists(const DblVec& x, DblVec& dists) {   // :124-128
-  vector<Collision> collisions;
-  GetCollisionsCached(x, collisions);
-  CollisionsToDistances(collisions, m_link2ind, dists);
-}
-
-void SingleTimestepCollisionEvaluator::CalcDistExpressions(const DblVec& x, vector<AffExpr>& exprs) {   // :131-136
-  vector<Collision> collisions;
-  GetCollisionsCached(x, collisions);
-  DblVec dofvals = getDblVec(x, m_vars);
-  CollisionsToDistanceExpressions(collisions, *m_rad, m_link2ind, m_vars, dofvals, exprs, false);
-}
-
-CastCollisionEvaluator::CastCollisionEvaluator(ConfigurationPtr rad, const VarVector& vars0, const VarVector& vars1)   // :140-154
-    : m_env(rad->GetEnv()), m_cc(CollisionChecker::GetOrCreate(*m_env)), m_rad(rad), m_vars0(vars0), m_vars1(vars1), m_filterMask(-1) {
-  vector<int> inds;
-  rad->GetAffectedLinks(m_links, true, inds);
-  for (size_t i = 0; i < m_links.size(); ++i) m_link2ind[m_links[i].get()] = inds[i];
-}
-
-void CastCollisionEvaluator::CalcCollisions(const DblVec& x, vector<Collision>& collisions) {   // :156-161
-  DblVec dofvals0 = getDblVec(x, m_vars0);
-  DblVec dofvals1 = getDblVec(x, m_vars1);
-  m_rad->SetDOFValues(dofvals0);
-  m_cc->CastVsAll(*m_rad, m_links, dofvals0, dofvals1, collisions);
-}
-
-void CastCollisionEvaluator::CalcDistExpressions(const DblVec& x, vector<AffExpr>& exprs) {   // :162-168
-  vector<Collision> collisions;
-  GetCollisionsCached(x, collisions);
-  DblVec dofvals0 = getDblVec(x, m_vars0);
-  DblVec dofvals1 = getDblVec(x, m_vars1);
-  CollisionsToDistanceExpressions(collisions, *m_rad, m_link2ind, m_vars0, m_vars1, dofvals0, dofvals1, exprs);
-}
-
-void CastCollisionEvaluator::CalcDists(const DblVec& x, DblVec& dists) {   // :169-173
-  vector<Collision> collisions;
-  GetCollisionsCached(x, collisions);
-  CollisionsToDistances(collisions, m_link2ind, dists);
-}
-
-CollisionCost::CollisionCost(double dist_pen, double coeff, ConfigurationPtr rad, const VarVector& vars)   // :196-199
-    : m_calc(new SingleTimestepCollisionEvaluator(rad, vars)), m_dist_pen(dist_pen), m_coeff(coeff) {}
-CollisionCost::CollisionCost(double dist_pen, double coeff, ConfigurationPtr rad, const VarVector& vars0, const VarVector& vars1)   // :201-204
-    : m_calc(new CastCollisionEvaluator(rad, vars0, vars1)), m_dist_pen(dist_pen), m_coeff(coeff) {}
-
-ConvexObjectivePtr CollisionCost::convex(const DblVec& x) {   // :205-214
-  ConvexObjectivePtr out(new ConvexObjective);
-  vector<AffExpr> exprs;
-  m_calc->CalcDistExpressions(x, exprs);
-  for (size_t i = 0; i < exprs.size(); ++i) {
-    AffExpr viol = exprSub(AffExpr(m_dist_pen), exprs[i]);
-    out->addHinge(viol, m_coeff);
-  }
-  return out;
-}
-
-double CollisionCost::value(const DblVec& x) {   // :215-223
-  DblVec dists;
-  m_calc->CalcDists(x, dists);
-  double out = 0;
-  for (size_t i = 0; i < dists.size(); ++i) out += pospart(m_dist_pen - dists[i]) * m_coeff;
-  return out;
-}
-
-CollisionConstraint::CollisionConstraint(double dist_pen, double coeff, ConfigurationPtr rad, const VarVector& vars)   // :233-237
-    : m_calc(new SingleTimestepCollisionEvaluator(rad, vars)), m_dist_pen(dist_pen), m_coeff(coeff) {}
-CollisionConstraint::CollisionConstraint(double dist_pen, double coeff, ConfigurationPtr rad, const VarVector& vars0, const VarVector& vars1)   // :239-243
-    : m_calc(new CastCollisionEvaluator(rad, vars0, vars1)), m_dist_pen(dist_pen), m_coeff(coeff) {}
-
-ConvexConstraintsPtr CollisionConstraint::convex(const DblVec& x) {   // :244-253
-  ConvexConstraintsPtr out(new ConvexConstraints);
-  vector<AffExpr> exprs;
-  m_calc->CalcDistExpressions(x, exprs);
-  for (size_t i = 0; i < exprs.size(); ++i) {
-    AffExpr viol = exprSub(AffExpr(m_dist_pen), exprs[i]);
-    out->addIneqCnt(exprMult(viol, m_coeff));
-  }
-  return out;
-}
-
-DblVec CollisionConstraint::value(const DblVec& x) {   // :254-262
-  DblVec dists;
-  m_calc->CalcDists(x, dists);
-  DblVec out(dists.size());
-  for (size_t i = 0; i < dists.size(); ++i) out[i] = pospart(m_dist_pen - dists[i]) * m_coeff;
-  return out;
 }
 
 }  // namespace trajopt

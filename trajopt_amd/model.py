@@ -13,6 +13,7 @@ GROUP_ROBOT, GROUP_KINBODY = 1, 2                      # collision_checker.hpp:3
 CC_NONE, CC_TIME0, CC_TIME1, CC_BETWEEN = 0, 1, 2, 3   # collision_checker.hpp:12-17
 J_FIXED, J_REVOLUTE, J_PRISMATIC = 0, 1, 2
 DOF_X, DOF_Y, DOF_Z, DOF_ROTAXIS = 1, 2, 4, 8          # OpenRAVE DOFAffine
+DOF_GRABBED = -2                                       # dof of a fixed link: a grabbed body's link (TOHC_DOF_GRABBED)
 IDENT7 = (1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
 
 
@@ -143,6 +144,12 @@ class RobotModel:
             self.n_dof = max(self.n_dof, dof + 1)
         return len(self.parent) - 1
 
+    def grab(self, grabber, T_in_grabber, obj, name=None):
+        """robot->Grab(body, grabberLink): one link of the grabbed body (its object `obj`), rigidly attached to link
+        `grabber` at pose T_in_grabber.  GetAffectedLinks lists it whether or not an active DOF moves it, and its Jacobian
+        is the grabber's (configuration_space.cpp:120-131)."""
+        return self.add_link(grabber, T_in_grabber, J_FIXED, dof=DOF_GRABBED, obj=obj, name=name or "grabbed%d" % len(self.parent))
+
     def set_active(self, joint_inds, affine=0, rot_axis=(0, 0, 1)):
         """RobotAndDOF(robot, joint_inds, affinedofs, rotationaxis)."""
         self.joint_inds = [int(j) for j in joint_inds]
@@ -179,7 +186,7 @@ class RobotModel:
         for i in range(self.n_links):
             if self.link_obj[i] < 0:
                 continue
-            aff = self.affine > 0
+            aff = self.affine > 0 or self.dof[i] == DOF_GRABBED   # grabbed links are listed unconditionally (:120-131)
             j = i
             while j >= 0 and not aff:
                 if self.jtype[j] != J_FIXED and self.dof[j] in active:
