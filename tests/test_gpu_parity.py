@@ -334,6 +334,66 @@ def test_grabbed_bodies(eng):
     w.close()
 
 
+def test_device_fk_and_jacobian_rows_closed_forms(eng):
+    """The gradient half of the metric against forms that do not come from the build's own FK model (OpenRAVE, which would
+    pin it, is absent -- DESIGN.md 2): (i) data/three_links.robot.xml, a planar 3R arm: k_fk's link poses against the
+    closed-form chain, k_finish's rows against n . (z x (p - o_j)) with the joint origins o_j in closed form; (ii) a free
+    rigid body driven by X | Y | Z | rotation about z: rows against [I | skew] (src/sandbox/incremental_rb.hpp:45-54)."""
+    # (i) planar 3R
+    s = M.Scene()
+    rb = synth.three_links(s)
+    ids, boxT = synth.add_boxes(s, [((.05, .05, .05), synth.T7((0.30, 0.12, 0.0))), ((.04, .2, .05), synth.T7((0.12, 0.20, 0.0), (0, 0, 1), 0.4))])
+    s.finalize(); rb.finalize()
+    static_T = synth.static_poses(s, ids, boxT)
+    eng.upload_scene(s, static_T)
+    eng.upload_robot(rb)
+    rng = np.random.default_rng(5)
+    Q = rng.uniform(-1.2, 1.2, size=(6, 3))
+    fk = eng.forward_kinematics(Q)
+    L = 0.16
+    for q, Tl in zip(Q, fk):
+        a1, a2, a3 = q[0], q[0] + q[1], q.sum()
+        o1 = np.zeros(3); o2 = np.array([L * np.cos(a1), L * np.sin(a1), 0]); o3 = o2 + [L * np.cos(a2), L * np.sin(a2), 0]
+        for link, o, ang in ((1, o1, a1), (2, o2, a2), (3, o3, a3)):
+            assert np.allclose(Tl[link][4:], o, atol=1e-14)
+            assert np.allclose(Tl[link][:4], [np.cos(ang / 2), 0, 0, np.sin(ang / 2)], atol=1e-14)
+    eng.set_contact_distance(0.25)
+    rec, g = eng.links_vs_all_batch(Q[:, None, :].reshape(6, 3), 6, 1, filter_mask=M.GROUP_KINBODY)
+    assert len(rec) >= 6
+    arm = {o: i for i, o in enumerate(rb.link_obj) if o >= 0}     # object -> link index (1, 2, 3)
+    z = np.array([0.0, 0.0, 1.0])
+    for r, row in zip(rec, g[:, 0]):
+        q = Q[r["problem"]]
+        a1, a2 = q[0], q[0] + q[1]
+        origins = [np.zeros(3), np.array([L * np.cos(a1), L * np.sin(a1), 0])]
+        origins.append(origins[1] + [L * np.cos(a2), L * np.sin(a2), 0])
+        want = np.zeros(3)
+        for obj, pt, sign in ((r["idA"], r["ptA"], 1.0), (r["idB"], r["ptB"], -1.0)):   # collision_terms.cpp:44-56
+            if obj in arm:
+                for j in range(arm[obj]):                                                # joints 0 .. link-1 move the link
+                    want[j] += sign * r["n"] @ np.cross(z, pt - origins[j])
+        assert np.allclose(row, want, rtol=1e-12, atol=1e-14)
+        assert abs(r["const0"] + row @ q - r["dist"]) < 1e-13
+    # (ii) free rigid body
+    s2 = M.Scene()
+    bot = synth.boxbot(s2)
+    bot.set_active([], M.DOF_X | M.DOF_Y | M.DOF_Z | M.DOF_ROTAXIS, (0, 0, 1))
+    ids2, boxT2 = synth.add_boxes(s2, [((.5, .5, .5), M.IDENT7)])
+    s2.finalize(); bot.finalize()
+    st2 = synth.static_poses(s2, ids2, boxT2)
+    eng.upload_scene(s2, st2)
+    eng.upload_robot(bot)
+    eng.set_contact_distance(0.3)
+    X = np.array([[1.15, 0.2, 0.1, 0.3], [-0.1, 1.2, -0.2, -0.6], [0.3, -0.2, 1.1, 1.0]])
+    rec, g = eng.links_vs_all_batch(X, 3, 1)
+    assert len(rec) == 3
+    for r, row in zip(rec, g[:, 0]):
+        x = X[r["problem"]]
+        sign, pt = (1.0, r["ptA"]) if r["idA"] == bot.link_obj[0] else (-1.0, r["ptB"])
+        J = np.concatenate([np.eye(3), np.cross(z, pt - x[:3])[:, None]], axis=1)        # [I | z x (p - o)]
+        assert np.allclose(row, sign * r["n"] @ J, rtol=1e-12, atol=1e-14)
+
+
 def test_allowed_matrix_and_group64_agree(eng):
     s, rb, static_T = _arm_world("rightarm", TABLE)
     eng.upload_scene(s, static_T)
