@@ -10,6 +10,8 @@ of those ranks.  One rank per GPU, problems partitioned over the ranks, no data-
 Workloads (config.workload):
   fullbody   (default) BASELINE.json configs[3] -- full-body PR2-like robot (K=18), 100 timesteps, against a 4096-hull
              convex soup, d = 0.09 -- batched as `problems_per_gpu` (64) independent multi-start trajectories per GPU;
+  fullbody42 a side line: the same with every hull at its full 42 vertices (the default's hulls average 16: the 42
+             support directions of a 120-point blob often pick the same point);
   multistart BASELINE.json configs[4], one GPU's share: 1024 independent python_examples/benchmark.py-shaped problems
              (right arm K=7, T=11, discrete + cast) in the reference's kitchen_counter world (52 boxes).
 One STEP = one SQP linearization of every problem on the rank: the discrete collision cost (self collision included)
@@ -70,7 +72,7 @@ def build_world(config, rank, world, problems):
         dofs = np.concatenate([synth.benchmark_trajectories(rb, np.random.default_rng(1000 + g), 1) for g in range(lo, hi)])
         caps = (max(1 << 22, problems * (1 << 12)), max(1 << 20, problems * 2048))
     else:
-        s, rb, static_T, d = synth.config_fullbody_soup()
+        s, rb, static_T, d = synth.config_fullbody_soup(npts=0 if config == "fullbody42" else 120)
         dofs = np.stack([synth.fullbody_trajectory(rb, np.random.default_rng(1000 + g), 100) for g in range(lo, hi)])
         caps = (max(1 << 23, problems * (1 << 16)), max(1 << 21, problems * 40000))   # ~30 K GJK pairs / 25 K records per problem and step
     cc = CC.HIPCollisionChecker(s, static_T, None, device=rank_device(rank))
@@ -84,8 +86,9 @@ def workload_text(config, P, T, K):
     if config == "multistart":
         return ("configs[4], one GPU's share: %d independent benchmark.py-shaped problems (right arm K=%d, T=%d, discrete+cast collision "
                 "costs with gradient rows) in the reference's kitchen_counter world (52 boxes), d=0.09" % (P, K, T))
-    return ("configs[3]: full-body PR2-like (K=%d) x %d timesteps vs 4096-hull convex soup, d=0.09, discrete+cast collision costs with "
-            "gradient rows; %d independent multi-start problems per GPU" % (K, T, P))
+    return ("configs[3]%s: full-body PR2-like (K=%d) x %d timesteps vs 4096-hull convex soup, d=0.09, discrete+cast collision costs with "
+            "gradient rows; %d independent multi-start problems per GPU"
+            % (" with full 42-vertex hulls (every blob dense enough that the 42 support directions pick distinct points)" if config == "fullbody42" else "", K, T, P))
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -160,7 +163,7 @@ def cpu_worker(idx, n, problems, budget_s, config):
         s, rb, static_T, d = synth.config_benchmark_scene("kitchen_counter")
         trajs = np.concatenate([synth.benchmark_trajectories(rb, np.random.default_rng(1000 + g), 1) for g in mine])
     else:
-        s, rb, static_T, d = synth.config_fullbody_soup()
+        s, rb, static_T, d = synth.config_fullbody_soup(npts=0 if config == "fullbody42" else 120)
         trajs = np.stack([synth.fullbody_trajectory(rb, np.random.default_rng(1000 + g), 100) for g in mine])
     cb = cpu_baseline(s, rb, static_T, d, allowed, trajs, budget_s=budget_s, only="reference" if B.ref_available() else "port")
     k = "reference" if "reference" in cb else "port"
@@ -191,7 +194,7 @@ def cpu_baseline_all_cores(allowed, problems, config, budget_s=10.0):
 # the newest committed summary under profiles/ (made by scripts/profile_bench.sh on this workload), never typed in
 # ----------------------------------------------------------------------------------------------------------------
 def profile_numbers(config):
-    want = "_ms_" if config == "multistart" else "_fb_"
+    want = {"multistart": "_ms_", "fullbody42": "_fb42_"}.get(config, "_fb_")
     def newest(suffix):
         fs = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*" + suffix)) if "rays" not in f and want in os.path.basename(f))
         return fs[-1] if fs else None
@@ -261,7 +264,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=["fullbody", "multistart"], default="fullbody")
+    ap.add_argument("--config", choices=["fullbody", "fullbody42", "multistart"], default="fullbody")
     ap.add_argument("--problems-per-gpu", type=int, default=None, help="default: 64 (fullbody), 1024 (multistart)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K-step block until this much has been timed; the median block is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -465,6 +465,17 @@ def test_linearization_is_first_order_accurate(built):
     w.close()
 
 
+def test_sanitizer_run_of_oracle_and_device_source(built):
+    """the C oracle and the host build of the DEVICE narrowphase source under AddressSanitizer +
+    UndefinedBehaviorSanitizer (`make -C oracle san`: a standalone driver over random scenes with boxes, 4..64-vertex
+    hulls, spheres, cylinders and compounds -- discrete, cast, sweeps, rays, FK + linearization), which also compares the
+    two bit for bit.  Any sanitizer report aborts the driver."""
+    import subprocess
+    p = subprocess.run(["make", "-C", os.path.join(util.ROOT, "oracle"), "san"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "san_driver: OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "runtime error" not in p.stderr and "AddressSanitizer" not in p.stderr
+
+
 # ---- C-ABI surface ------------------------------------------------------------------------------------------
 def test_abi_library_exports_every_declared_symbol(built):
     from trajopt_amd import engine

@@ -55,6 +55,9 @@ def dirs42():
 
 def blob_hull(rng, scale=(0.05, 0.05, 0.15), npts=200, nverts=42, center=(0, 0, 0)):
     """Vertices (fp32) of the hull of `nverts` support directions of a random anisotropic blob."""
+    if npts == 0:   # a smooth blob: its support points along the 42 directions are 42 distinct vertices (radius ~2.4 sigma +- 8 %)
+        assert nverts == 42
+        return (dirs42() * np.asarray(scale) * (2.4 * rng.uniform(0.92, 1.08, size=(42, 1))) + np.asarray(center)).astype(np.float32)
     pts = rng.normal(size=(npts, 3)) * np.asarray(scale) + np.asarray(center)
     if nverts == 42:
         d = dirs42()
@@ -121,7 +124,7 @@ def three_links(scene):
     return r
 
 
-def pr2_like(scene, seed=0, active="rightarm"):
+def pr2_like(scene, seed=0, active="rightarm", npts=120):
     """Synthetic PR2-like robot: ~45 links, 19 robot DOFs.
 
     DOF layout: 0 torso, 1-7 right arm, 8-14 left arm, 15/16 right/left gripper, 17/18 head pan/tilt.
@@ -134,7 +137,7 @@ def pr2_like(scene, seed=0, active="rightarm"):
     def hulls(n, scale, centers, nv=42):
         ch = []
         for i in range(n):
-            h = scene.add_hull(blob_hull(rng, scale=scale, nverts=nv, npts=120))
+            h = scene.add_hull(blob_hull(rng, scale=scale, nverts=nv, npts=npts if (npts or nv == 42) else 120))
             ch.append((h, T7(centers[i])))
         return ch
 
@@ -205,7 +208,7 @@ def add_boxes(scene, boxes, name="env"):
     return ids, np.array([T for _, T in boxes], float).reshape(-1, 7)
 
 
-def convex_soup(scene, n_hulls=4096, seed=2, extent=3.0, sigma=0.03, center=(1.5, 0.0)):
+def convex_soup(scene, n_hulls=4096, seed=2, extent=3.0, sigma=0.03, center=(1.5, 0.0), npts=120):
     """SURVEY config 4: ONE object with n convex children (trajoptpy/convex_soup.py makes one link with N trimesh
     geoms), each the 42-direction hull of a sigma=3 cm blob centred on a 2.5-D heightfield over extent x extent m."""
     rng = np.random.default_rng(seed)
@@ -217,7 +220,7 @@ def convex_soup(scene, n_hulls=4096, seed=2, extent=3.0, sigma=0.03, center=(1.5
     for k in range(n_hulls):
         x, y = xs[k % g], ys[k // g]
         z = 0.75 + 0.15 * np.sin(2.1 * x + ph[0]) * np.cos(1.7 * y + ph[1]) + 0.08 * np.sin(5.3 * x + ph[2]) * np.sin(4.1 * y + ph[3])
-        pts = blob_hull(rng, scale=(sigma, sigma, sigma), npts=120, nverts=42)
+        pts = blob_hull(rng, scale=(sigma, sigma, sigma), npts=npts, nverts=42)
         ch.append((scene.add_hull(pts), T7((x, y, z))))
     return scene.add_object(ch, M.GROUP_KINBODY, compound=True, name="soup")
 
@@ -248,12 +251,15 @@ def config_arm_table(seed=0):
     return s, rb, static_poses(s, ids, T), 0.065
 
 
-def config_fullbody_soup(n_hulls=4096, seed=2):
+def config_fullbody_soup(n_hulls=4096, seed=2, npts=120):
     """Config 4: full-body PR2-like robot (K=18: torso + 2 arms + base x,y,theta) in front of a 4096-hull convex soup
-    (one object with 4096 convex children on a 3 x 3 m heightfield); d = 0.05 + 0.04."""
+    (one object with 4096 convex children on a 3 x 3 m heightfield); d = 0.05 + 0.04.
+    npts: points per random blob whose 42 support points make a hull.  With 120 (the default workload) many of the 42
+    directions pick the same point: ~16 vertices per hull.  npts = 0: smooth blobs, all 42 support points distinct --
+    the hull size btShapeHull gives a dense mesh (bench.py --config fullbody42)."""
     s = M.Scene()
-    rb = pr2_like(s, seed=0, active="fullbody")
-    convex_soup(s, n_hulls=n_hulls, seed=seed, center=(2.05, 0.0))
+    rb = pr2_like(s, seed=0, active="fullbody", npts=npts)
+    convex_soup(s, n_hulls=n_hulls, seed=seed, center=(2.05, 0.0), npts=npts)
     s.finalize(); rb.finalize()
     return s, rb, static_poses(s), 0.09
 
