@@ -356,7 +356,47 @@ def main():
 
     # host-delivered rate on rank 0's data (never `value`)
     api = lat_ms = lat_dev_ms = sweep_ms = n_sw = None
+    hinge = None
     if rank == 0 and not args.hot_path_only:
+        # The same workload delivered as what the SQP host feeds its QP solver: hinge rows + BPMPD columns
+        # assembled on the device (tohc_fetch_hinges).  (a) one linearization at a time; (b) pipelined over batches of
+        # problems, as a multi-start job runs: batch i+1 computes while batch i's block is assembled and copied.
+        dp = 0.05
+        eng.stage_dofs(dofs, P, T)
+        eng.enqueue_links_vs_all(-1, True, append=False)
+        eng.enqueue_cast_vs_all(1, True, append=True)
+        h = eng.fetch_hinges(dp, dp, copy=False)           # warm-up: buffers
+        ta = time.perf_counter()
+        pe = 0
+        for _ in range(3):
+            eng.stage_dofs(dofs, P, T)
+            eng.enqueue_links_vs_all(-1, True, append=False)
+            eng.enqueue_cast_vs_all(1, True, append=True)
+            h = eng.fetch_hinges(dp, dp, copy=False)
+            pe += eng.counters()["pair_evals"]
+        hinge_sync = pe / (time.perf_counter() - ta)
+        hbytes = int(h["n_rows"] * 20 + h["nnz"] * 12 + (len(h["col_off"]) + len(h["row_off"])) * 8)
+        eng.stage_dofs(dofs, P, T)
+        eng.enqueue_links_vs_all(-1, True, append=False)
+        eng.enqueue_cast_vs_all(1, True, append=True)
+        NB = 16
+        pe = 0
+        for b in range(NB + 2):
+            if b == 2:                                     # two untimed batches fill the pipeline (and the second buffer set)
+                ta = time.perf_counter()
+                pe = 0
+            eng.fetch_hinges_begin(dp, dp)                 # waits for batch i; its counters are final
+            pe += eng.counters()["pair_evals"]
+            eng.stage_dofs(dofs, P, T)                     # batch i+1
+            eng.enqueue_links_vs_all(-1, True, append=False)
+            eng.enqueue_cast_vs_all(1, True, append=True)
+            h = eng.fetch_hinges_end(copy=False)           # batch i in host memory while batch i+1 computes
+        hinge_pipe = pe / (time.perf_counter() - ta)
+        eng.sync()
+        hinge = {"value_sync": hinge_sync, "value_pipelined": hinge_pipe, "batches_pipelined": NB, "rows_per_step": int(h["n_rows"]),
+                 "nonzeros_per_step": int(h["nnz"]), "bytes_per_step": hbytes, "contact_slab_bytes_per_step": int(h["n_rows"] * (152 + 16 * rb.K)),
+                 "what": "tohc_fetch_hinges: per problem rhs / dist / row_t per contact + the BPMPD columns (acolcnt, acolidx, acolnzs) of the "
+                         "trajectory variables, zeros dropped; pipelined = tohc_fetch_hinges_begin / _end around the next batch's enqueues"}
         ta = time.perf_counter()
         pe = 0
         for _ in range(3):
@@ -449,6 +489,8 @@ def main():
                        "parallelism": "problems sharded over %d GPU(s), no collective" % world},
             "value_scope": "device slab complete (tohc_sync); no D2H, no canonical order -- see value_host_delivered",
             "value_host_delivered": api,
+            "value_host_delivered_scope": "stage + enqueue + tohc_fetch: every contact record (152 B) + 2K gradient doubles in canonical order in pinned host memory, one linearization at a time",
+            "value_host_delivered_hinges": hinge,
             "timed": {"blocks": len(blocks), "seconds_total": total, "block_seconds_min_median_max": [blocks[0][0], dt_max, blocks[-1][0]]},
             "pair_evals_per_step_per_gpu": dc["cum_pair_evals"] / S,
             "gjk_evals_per_step_per_gpu": dc["cum_gjk_evals"] / S,

@@ -152,6 +152,47 @@ int tohc_fetch(tohc_engine *e, const tohc_record **records, const double **grads
  * device buffers: no round trip through host memory.  No counterpart in the reference (single process, no GPU). */
 int tohc_fetch_device(tohc_engine *e, const tohc_record **d_records, const double **d_grads, int *n_records, int *row_doubles);
 
+/* replaces, for the collision costs of one linearization, everything between the contacts and the solver's input:
+ *   CollisionsToDistanceExpressions  src/trajopt/collision_terms.cpp:37-80     CollisionCost::convex  :205-214
+ *   ConvexObjective::addHinge        src/sco/modeling.cpp:22-29                BPMPDModel::optimize   src/sco/bpmpd_interface.cpp:320-372
+ * (SURVEY.md 8 f2).  The slab of the last enqueues (one discrete pass and / or one cast pass, with gradient rows) is put in
+ * canonical order and turned, ON THE DEVICE, into the rows and columns BPMPD takes; the host reads those instead of the
+ * 152 + 16 K bytes of every contact.  For problem p, with x[t*K + k] its trajectory variables and one new variable
+ * h_i >= 0 per contact i (rows row_off[p] .. row_off[p+1], canonical order):
+ *     row i:   dist_pen - (const_i + grad_i . x) - h_i <= 0          objective += coeff * h_i
+ *   rhs[i]     = -(dist_pen - const_i)                                (bpmpd rhs = -aff.constant; row bounds [-BIG, 0])
+ *   column (p, t, k) = entries col_off[c] .. col_off[c+1], c = (p*T + t)*K + k:  (col_idx = row within the problem,
+ *     0-based and ascending; col_val = -(d dist_i / d x[t*K+k])), exact zeros dropped as sco's simplify2 does -- acolcnt,
+ *     acolidx (before its +1), acolnzs of those variables.  Each h_i's own column is the single entry (i, -1).
+ *   dist[i] is the signed distance (CollisionCost::value = sum coeff * max(0, dist_pen - dist)); row_t[i] = the timestep
+ *     (cast: the first of the pair) | TOHC_HINGE_CAST: which cost object of the reference the row belongs to.
+ * Values are bit-identical to the reference's fp64 arithmetic on the same contacts.  All pointers are pinned host
+ * memory owned by the engine.
+ *
+ * tohc_fetch_hinges            = begin + end.
+ * tohc_fetch_hinges_begin      waits for the slab, starts sort + assembly + the copy of the per-row arrays on a stream of
+ *                              its own and returns; the next tohc_stage_dofs / enqueues may follow at once (they wait on
+ *                              the device only until the assembly has read the slab).
+ * tohc_fetch_hinges_end        waits for those, copies the columns (their size is known only now) and returns the block:
+ *                              called after the next linearization has been enqueued, the copy runs while the GPU
+ *                              computes.  One begin may be outstanding; a block stays valid until the second next begin
+ *                              (two host buffer sets alternate). */
+#define TOHC_HINGE_CAST (1 << 30)
+typedef struct tohc_hinges {
+  int32_t n_problems, T, K, gap;
+  int64_t n_rows, nnz;
+  const int64_t *row_off;   /* [n_problems + 1]          */
+  const double *rhs;        /* [n_rows]                  */
+  const double *dist;       /* [n_rows]                  */
+  const int32_t *row_t;     /* [n_rows]                  */
+  const int64_t *col_off;   /* [n_problems * T * K + 1]  */
+  const int32_t *col_idx;   /* [nnz]                     */
+  const double *col_val;    /* [nnz]                     */
+} tohc_hinges;
+int tohc_fetch_hinges(tohc_engine *e, double dist_pen_discrete, double dist_pen_cast, tohc_hinges *out);
+int tohc_fetch_hinges_begin(tohc_engine *e, double dist_pen_discrete, double dist_pen_cast);
+int tohc_fetch_hinges_end(tohc_engine *e, tohc_hinges *out);
+
 /* replaces LinksVsAll / CastVsAll on explicit poses (no robot model needed): the reference reads poses from the
  * OpenRAVE environment at call time (UpdateBulletFromRave, bullet_collision_checker.cpp:648-653).
  * obj_T: [n_sets][n_objects][7]; query: object ids.  No Jacobians (no kinematic model). */

@@ -394,6 +394,83 @@ def test_device_fk_and_jacobian_rows_closed_forms(eng):
         assert np.allclose(row, sign * r["n"] @ J, rtol=1e-12, atol=1e-14)
 
 
+def test_hinge_block_equals_host_assembly(eng):
+    """tohc_fetch_hinges -- the hinge rows and BPMPD columns assembled on the device -- against the same
+    block built on the host from the fetched contact slab the way sco does it (collision_checker.bpmpd_collision_block:
+    CollisionsToDistanceExpressions -> convex -> addHinge -> BPMPDModel::optimize with simplify2): BIT-identical, for a
+    discrete + cast slab of several problems, a cast pass with gap 2, a discrete-only slab, an empty slab; and the
+    begin / end pair overlapping the next linearization returns the same block as the synchronous call."""
+    from trajopt_amd import collision_checker as CC, engine
+    s, rb, static_T = _arm_world("fullbody", TABLE + [((.2, .3, .4), synth.T7((0.6, -0.6, 0.4), (0, 0, 1), 0.5))])
+    rng = np.random.default_rng(17)
+    B_, T_ = 3, 9
+    dofs = np.stack([synth.straight_line(rng.uniform(-0.6, 0.6, rb.K), rng.uniform(-0.9, 0.9, rb.K), T_) for _ in range(B_)])
+    eng.upload_scene(s, static_T)
+    eng.upload_robot(rb)
+    eng.set_contact_distance(0.12)
+    eng.stage_dofs(dofs, B_, T_)
+
+    def same(h, ref, tag):
+        for k in ("B", "T", "K", "gap", "n_rows", "nnz"):
+            assert h[k] == ref[k], (tag, k, h[k], ref[k])
+        for k in ("row_off", "rhs", "dist", "row_t", "col_off", "col_idx", "col_val"):
+            assert h[k].dtype == ref[k].dtype and h[k].tobytes() == ref[k].tobytes(), (tag, k)
+
+    for gap, passes in ((1, "dc"), (2, "dc"), (0, "d"), (1, "c")):
+        first = True
+        for kind in passes:
+            if kind == "d":
+                eng.enqueue_links_vs_all(-1, True, append=not first)
+            else:
+                eng.enqueue_cast_vs_all(gap, True, append=not first)
+            first = False
+        rec, g = eng.fetch()
+        assert len(rec) > 50
+        h = eng.fetch_hinges(0.05, 0.03)
+        ref = CC.bpmpd_collision_block(rec, g, B_, T_, rb.K, gap if "c" in passes else 0, 0.05, 0.03)
+        same(h, ref, "gap %d %s" % (gap, passes))
+        assert h["nnz"] < h["n_rows"] * 2 * rb.K          # structural zeros (joints that do not move the link) are dropped
+        # the rows say what the reference's costs say: hinge argument at x = dist_pen - dist
+        x = dofs.reshape(B_, -1)
+        for p_ in range(B_):
+            r0, r1 = h["row_off"][p_], h["row_off"][p_ + 1]
+            viol = -h["rhs"][r0:r1].copy()
+            for c in range(T_ * rb.K):
+                a, b = h["col_off"][p_ * T_ * rb.K + c], h["col_off"][p_ * T_ * rb.K + c + 1]
+                np.add.at(viol, h["col_idx"][a:b], h["col_val"][a:b] * x[p_, c])
+            pen = np.where(h["row_t"][r0:r1] & engine.HINGE_CAST, 0.03, 0.05)
+            assert np.allclose(viol, pen - h["dist"][r0:r1], atol=1e-12)
+    # begin / end around the next linearization
+    eng.enqueue_links_vs_all(-1, True, append=False)
+    eng.enqueue_cast_vs_all(1, True, append=True)
+    want = eng.fetch_hinges(0.05, 0.05)
+    eng.enqueue_links_vs_all(-1, True, append=False)
+    eng.enqueue_cast_vs_all(1, True, append=True)
+    eng.fetch_hinges_begin(0.05, 0.05)
+    with pytest.raises(engine.EngineError):
+        eng.fetch_hinges_begin(0.05, 0.05)               # one begin at a time
+    eng.stage_dofs(dofs[::-1].copy(), B_, T_)            # the next batch: other trajectories
+    eng.enqueue_links_vs_all(-1, True, append=False)
+    eng.enqueue_cast_vs_all(1, True, append=True)
+    got = eng.fetch_hinges_end()
+    same(got, want, "pipelined")
+    nxt = eng.fetch_hinges(0.05, 0.05)
+    assert nxt["n_rows"] == want["n_rows"] and np.array_equal(nxt["row_off"], np.concatenate([[0], np.cumsum(np.diff(want["row_off"])[::-1])]))
+    with pytest.raises(engine.EngineError):
+        eng.fetch_hinges_end()
+    # an empty slab (nothing within the contact distance)
+    eng.set_contact_distance(0.0)
+    far = dofs.copy(); far[..., -3] += 50.0               # the base 50 m away
+    eng.stage_dofs(far, B_, T_)
+    eng.enqueue_links_vs_all(M.GROUP_KINBODY, True, append=False)
+    h0 = eng.fetch_hinges(0.05)
+    assert h0["n_rows"] == 0 and h0["nnz"] == 0 and not h0["col_off"].any() and not h0["row_off"].any()
+    # a slab without gradient rows cannot be turned into hinges
+    eng.enqueue_links_vs_all(-1, False, append=False)
+    with pytest.raises(engine.EngineError):
+        eng.fetch_hinges(0.05)
+
+
 def test_allowed_matrix_and_group64_agree(eng):
     s, rb, static_T = _arm_world("rightarm", TABLE)
     eng.upload_scene(s, static_T)

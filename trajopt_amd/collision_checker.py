@@ -247,6 +247,44 @@ def aff_exprs(rec, grads, cast):
     return const, one_minus_t[:, None] * grads[:, 0], t[:, None] * grads[:, 1]
 
 
+def bpmpd_collision_block(rec, grads, B, T, K, gap, dist_pen_discrete, dist_pen_cast):
+    """What sco hands BPMPD for the collision hinges of one linearization, built on the HOST from the contact slab the
+    way the reference does it -- the checker of tohc_fetch_hinges:
+      CollisionsToDistanceExpressions (collision_terms.cpp:37-80) -> CollisionCost::convex (:205-214: viol = dist_pen - expr)
+      -> ConvexObjective::addHinge (modeling.cpp:22-29: row viol - h <= 0) -> BPMPDModel::optimize (bpmpd_interface.cpp:352-369:
+      rhs = -constant, per variable the (row, value) list through simplify2: zeros dropped, rows ascending).
+    rec / grads: one slab in canonical order.  Returns the dict Engine.fetch_hinges returns."""
+    n = len(rec)
+    cast = rec["cctype"] != 0
+    const = rec["const0"].copy()
+    wa, wb = np.ones(n), np.zeros(n)
+    wa[cast] = (np.float32(1) - rec["time"][cast]).astype(float)      # `1-collisions[i].time` is float arithmetic (:73)
+    wb[cast] = rec["time"][cast].astype(float)
+    const[cast] = wa[cast] * rec["const0"][cast] + wb[cast] * rec["const1"][cast]
+    pen = np.where(cast, dist_pen_cast, dist_pen_discrete)
+    rhs = -(pen - const)
+    row_off = np.searchsorted(rec["problem"], np.arange(B + 1)).astype(np.int64)
+    cols = [[] for _ in range(B * T * K)]
+    for i in range(n):                                                # rows in canonical order = ascending within a column
+        p, t = int(rec["problem"][i]), int(rec["t"][i])
+        r = i - int(row_off[p])
+        v0 = -(wa[i] * grads[i, 0])
+        for k in np.nonzero(v0 != 0)[0]:
+            cols[(p * T + t) * K + k].append((r, v0[k]))
+        if cast[i]:
+            v1 = -(wb[i] * grads[i, 1])
+            for k in np.nonzero(v1 != 0)[0]:
+                cols[(p * T + t + gap) * K + k].append((r, v1[k]))
+    for c in cols:
+        c.sort(key=lambda e: e[0])                                    # simplify2's std::map order (no row repeats within a column)
+    col_off = np.concatenate([[0], np.cumsum([len(c) for c in cols])]).astype(np.int64)
+    col_idx = np.array([e[0] for c in cols for e in c], np.int32)
+    col_val = np.array([e[1] for c in cols for e in c], np.float64)
+    from .engine import HINGE_CAST
+    return dict(B=B, T=T, K=K, gap=gap, n_rows=n, nnz=len(col_val), row_off=row_off, rhs=rhs, dist=rec["dist"].copy(),
+                row_t=(rec["t"] | np.where(cast, HINGE_CAST, 0)).astype(np.int32), col_off=col_off, col_idx=col_idx, col_val=col_val)
+
+
 class CollisionCost:
     """collision_terms.cpp:196-223: hinge cost coeff * max(0, dist_pen - dist) per contact."""
 

@@ -22,6 +22,7 @@
 #include "../../include/trajopt_hipcc.h"
 #include "tohc_sort.h"
 #include "tohc_kernels.h"
+#include "tohc_hinge.h"
 
 using namespace tohc;
 
@@ -169,6 +170,7 @@ struct tohc_engine {
   std::vector<hipEvent_t> events;   // RING * NEV
   DBuf<unsigned int> d_nrec;        // shared record counter
   HBuf<unsigned int> h_nrec;
+  HBuf<double> h_dofs;              // pinned staging of the DOF vectors
   int staged_B = 0, staged_T = 0;
   bool staged = false;
   bool last_robot_mode = true, last_want_jac = false;   // of the current slab (set by the enqueue that starts it; appends must agree)
@@ -177,6 +179,30 @@ struct tohc_engine {
   // may then exceed what d_records holds, and the slab is truncated -- fetch refuses it (TOHC_E_STATE).
   int slab_state = 0;
   bool sorted_valid = false;   // d_sorted / d_gsorted hold the current slab in canonical order
+  // ---- hinge fetch (tohc_hinge.h): sort + assembly + copies on a stream of their own, so that they overlap the next
+  // linearization's kernels; two host buffer sets alternate
+  hipStream_t hinge_stream = nullptr;
+  hipEvent_t ev_slab_read = nullptr;    // the assembly has read d_records / d_grads: a new slab may overwrite them
+  hipEvent_t ev_hinge_small = nullptr;  // the per-row arrays and the column offsets are in host memory
+  bool slab_read_pending = false, hinge_open = false;
+  DBuf<uint64_t> d_hkeys;
+  DBuf<uint32_t> d_hidx;
+  DBuf<unsigned char> d_htmp;
+  DBuf<double> d_hrhs, d_hdist, d_hwa, d_hwb, d_hval;
+  DBuf<int32_t> d_hrowt, d_hcolidx;
+  DBuf<unsigned int> d_hseg, d_hcnt;
+  DBuf<long long> d_hrowoff, d_hcoloff;
+  struct HingeHost {
+    HBuf<double> rhs, dist, val;
+    HBuf<int32_t> row_t, idx;
+    HBuf<long long> row_off, col_off;
+    size_t n = 0;
+    int B = 0, T = 0, K = 0, gap = 0;
+  };
+  HingeHost hh[2];
+  int hinge_cur = 0;
+  // what the current slab holds, pass by pass (enqueue calls): the hinge assembly takes one discrete and / or one cast pass
+  int slab_B = 0, slab_disc_passes = 0, slab_cast_passes = 0, slab_gap = 0;
   int gjk_group = 1;  // lanes per pair in k_gjk: 1 (default), 16 or 64 (TOHC_GJK_GROUP)
   int pen_group = 1;   // lanes per pair in k_pen: 1, or 4 (hull vertices in registers; TOHC_PEN_GROUP=4: measured no faster, GJK2's LDS bookkeeping dominates)
   int epa_block = 64;  // threads per k_epa block (TOHC_EPA_BLOCK = 16 or 64)
@@ -206,6 +232,7 @@ static hipError_t quiesce(tohc_engine *e) {
   for (auto &ln : e->lane)
     if (ln.stream) { hipError_t r = hipStreamSynchronize(ln.stream); if (r != hipSuccess) return r; }
   if (e->tail_stream) { hipError_t r = hipStreamSynchronize(e->tail_stream); if (r != hipSuccess) return r; }
+  if (e->hinge_stream) { hipError_t r = hipStreamSynchronize(e->hinge_stream); if (r != hipSuccess) return r; }
   e->fk_done = false;
   return hipStreamSynchronize(e->stream);
 }
@@ -296,6 +323,12 @@ int tohc_create(tohc_engine **out, int device) {
     tohc_destroy(e);
     return TOHC_E_HIP;
   }
+  // (a high-priority stream for the assembly was tried: the whole pipeline got slower, 8.5 vs 5.4 ms per batch)
+  if (hipStreamCreateWithFlags(&e->hinge_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_slab_read, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_hinge_small, hipEventDisableTiming) != hipSuccess) {
+    tohc_destroy(e);
+    return TOHC_E_HIP;
+  }
   if (const char *mt = getenv("TOHC_MERGE_TAIL")) e->max_open = atoi(mt) != 0 ? TOHC_MAX_HEADS : 1;
   if (const char *eb = getenv("TOHC_EPA_BLOCK")) e->epa_block = atoi(eb) == 16 ? 16 : 64;
   if (const char *pg = getenv("TOHC_PEN_GROUP")) e->pen_group = atoi(pg) == 4 ? 4 : 1;
@@ -324,6 +357,9 @@ void tohc_destroy(tohc_engine *e) {
   }
   if (e->tail_stream) { (void)hipStreamSynchronize(e->tail_stream); (void)hipStreamDestroy(e->tail_stream); }
   if (e->tail_ranged) (void)hipEventDestroy(e->tail_ranged);
+  if (e->hinge_stream) { (void)hipStreamSynchronize(e->hinge_stream); (void)hipStreamDestroy(e->hinge_stream); }
+  if (e->ev_slab_read) (void)hipEventDestroy(e->ev_slab_read);
+  if (e->ev_hinge_small) (void)hipEventDestroy(e->ev_hinge_small);
   if (e->ev_fk) (void)hipEventDestroy(e->ev_fk);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -929,6 +965,10 @@ static int launchTail(tohc_engine *e) {
       else hipLaunchKernelGGL((k_tail_epa<16, 64, 2>), dim3(TOHC_EPA_GRID * 2), dim3(64), 0, ts, ta);
     }
   }
+  // A hinge assembly may still be reading the previous slab (tohc_fetch_hinges_begin): the broadphase, GJK and the
+  // penetration kernels of this one run beside it, only what writes records and gradient rows (k_finish, behind the
+  // range event) waits for it
+  if (e->slab_read_pending) HIPCHK(hipStreamWaitEvent(ts, e->ev_slab_read, 0));
   if (e->have_ranged) HIPCHK(hipStreamWaitEvent(ts, e->tail_ranged, 0));   // record ranges are reserved in enqueue order
   hipLaunchKernelGGL(k_tail_range, dim3(1), dim3(1), 0, ts, ta);   // also for passes without work: they reserve an empty range
   HIPCHK(hipEventRecord(evl[6], ts));
@@ -1061,6 +1101,7 @@ static int launchSweep(tohc_engine *e, const DynMap &dm, const int *d_qchildren,
   HIPCHK(hipStreamWaitEvent(s, e->ev_fk, 0));
   for (auto &other : e->lane)
     if (&other != &ln) HIPCHK(hipStreamWaitEvent(s, other.done, 0));
+  if (e->slab_read_pending) HIPCHK(hipStreamWaitEvent(s, e->ev_slab_read, 0));   // k_sweep writes records itself
   HIPCHK(hipMemsetAsync(e->d_cnt.p + slot, 0, sizeof(Counters), s));
   HIPCHK(hipMemsetAsync(e->d_nrec.p, 0, sizeof(unsigned int), s));
   cp.seg_cap = (unsigned int)(e->max_pairs / TOHC_NSHARD); cp.max_records = (unsigned int)e->max_records;
@@ -1129,13 +1170,17 @@ int tohc_stage_dofs(tohc_engine *e, const double *dofs, int B, int T) {
   for (auto &ln : e->lane) HIPCHK(hipStreamSynchronize(ln.stream));   // enqueues still reading the old tables
   HIPCHK(hipStreamSynchronize(e->tail_stream));
   e->fk_done = false;
-  HIPCHK(upload(e->d_dofs, dofs, n_sets * e->K, e->stream));
+  // through a pinned buffer: a copy from pageable memory is staged by the runtime and took 1.3 ms for the 0.9 MB of 64
+  // problems -- with the GPU idle -- against 0.1 ms this way (scripts/probe_hinges.py)
+  HIPCHK(e->h_dofs.reserve(n_sets * e->K));
+  memcpy(e->h_dofs.p, dofs, n_sets * e->K * sizeof(double));
+  HIPCHK(e->d_dofs.reserve(n_sets * e->K));
+  HIPCHK(hipMemcpyAsync(e->d_dofs.p, e->h_dofs.p, n_sets * e->K * sizeof(double), hipMemcpyHostToDevice, e->stream));
   HIPCHK(e->d_linkQT.reserve(n_sets * e->n_links * 7));
   HIPCHK(e->d_objQT.reserve(n_sets * std::max(e->n_dyn_objR, 1) * 7));
   HIPCHK(e->d_dynXf.reserve(n_sets * std::max(e->n_dyn_childrenR, 1) * 12));
   HIPCHK(e->d_dynAabb.reserve(n_sets * std::max(e->n_dyn_childrenR, 1) * 6));
-  HIPCHK(hipStreamSynchronize(e->stream));  // the caller's buffer may go away
-  e->staged_B = B; e->staged_T = T; e->staged = true;
+  e->staged_B = B; e->staged_T = T; e->staged = true;   // (the caller's buffer has been copied; FK follows on the same stream)
   return TOHC_OK;
 }
 
@@ -1173,6 +1218,9 @@ static int enqueueRobot(tohc_engine *e, int gap, int cast, int filter_mask, int 
   cp.T = T; cp.gap = cast ? gap : 0; cp.cast = cast; cp.filter_mask = filter_mask; cp.want_jac = want_jac; cp.d = e->d; cp.breaking = e->breaking;
   const int units = cast ? B * std::max(T - gap, 0) : B * T;
   e->last_sets = (int64_t)n_sets;
+  if (!append || (e->slab_state == 0 && e->pending.empty())) e->slab_B = B, e->slab_disc_passes = e->slab_cast_passes = 0, e->slab_gap = 0;
+  if (cast) { if (e->slab_cast_passes++ > 0 && e->slab_gap != gap) e->slab_gap = -1; else e->slab_gap = gap; }
+  else ++e->slab_disc_passes;
   // large enqueues are cut into unit ranges that run on different lanes: the kernels are latency bound, so
   // independent ranges overlap almost perfectly
   const int C = units >= 256 * e->chunks ? e->chunks : 1;
@@ -1316,6 +1364,93 @@ int tohc_fetch_device(tohc_engine *e, const tohc_record **d_records, const doubl
   if (d_grads) *d_grads = e->last_want_jac ? e->d_gsorted.p : nullptr;
   if (row_doubles) *row_doubles = e->last_want_jac ? 2 * K : 0;
   return TOHC_OK;
+}
+
+int tohc_fetch_hinges_begin(tohc_engine *e, double dist_pen_discrete, double dist_pen_cast) {
+  if (!e) return TOHC_E_INVALID;
+  if (e->hinge_open) return fail(e, TOHC_E_STATE, "fetch_hinges_begin: the previous begin has not been ended");
+  HIPCHK(hipSetDevice(e->device));
+  int rc = syncEngine(e);
+  if (rc != TOHC_OK) return rc;
+  if (e->slab_state != 1) return fail(e, TOHC_E_STATE, e->slab_state < 0 ? "fetch_hinges: the last sync of this slab failed; there is no valid slab" : "fetch_hinges: nothing has been enqueued");
+  if (!e->last_robot_mode || !e->last_want_jac) return fail(e, TOHC_E_STATE, "fetch_hinges: the slab holds no gradient rows (enqueue with want_jacobians on staged DOF vectors)");
+  if (e->slab_disc_passes > 1 || e->slab_cast_passes > 1 || e->slab_gap < 0)
+    return fail(e, TOHC_E_UNSUPPORTED, "fetch_hinges: the slab holds %d discrete and %d cast passes; one of each at most", e->slab_disc_passes, e->slab_cast_passes);
+  const int B = e->slab_B, T = e->last_T, K = e->K, gap = e->slab_cast_passes ? e->slab_gap : 0;
+  if (e->last_sets > SORT_MAX_SETS || e->n_children > SORT_MAX_CHILDREN || !e->children_in_object_order)
+    return fail(e, TOHC_E_UNSUPPORTED, "fetch_hinges: more than %d pose sets or %d geometries", SORT_MAX_SETS, SORT_MAX_CHILDREN);
+  const size_t n = std::min<size_t>(*e->h_nrec.p, e->d_records.cap);
+  const size_t ncols = (size_t)B * T * K, nseg = (size_t)B * T * 2;
+  if (ncols + 1 > 0x7fffffffull) return fail(e, TOHC_E_CAPACITY, "fetch_hinges: %zu trajectory variables", ncols);
+  hipStream_t s = e->hinge_stream;
+  tohc_engine::HingeHost &h = e->hh[e->hinge_cur];
+  h.n = n; h.B = B; h.T = T; h.K = K; h.gap = gap;
+  size_t tmpBytes = 0;
+  HIPCHK(sortTempBytes(std::max<size_t>(n, 1), &tmpBytes));
+  HIPCHK(e->d_htmp.reserve(tmpBytes)); HIPCHK(e->d_hkeys.reserve(2 * n + 2)); HIPCHK(e->d_hidx.reserve(2 * n + 2));
+  HIPCHK(e->d_hrhs.reserve(n)); HIPCHK(e->d_hdist.reserve(n)); HIPCHK(e->d_hwa.reserve(n)); HIPCHK(e->d_hwb.reserve(n)); HIPCHK(e->d_hrowt.reserve(n));
+  HIPCHK(e->d_hseg.reserve(nseg + 1)); HIPCHK(e->d_hrowoff.reserve((size_t)B + 1)); HIPCHK(e->d_hcnt.reserve(ncols)); HIPCHK(e->d_hcoloff.reserve(ncols + 1));
+  HIPCHK(e->d_hcolidx.reserve(n * 2 * (size_t)K)); HIPCHK(e->d_hval.reserve(n * 2 * (size_t)K));   // the bound: every coefficient non-zero
+  HIPCHK(h.rhs.reserve(n)); HIPCHK(h.dist.reserve(n)); HIPCHK(h.row_t.reserve(n)); HIPCHK(h.row_off.reserve((size_t)B + 1)); HIPCHK(h.col_off.reserve(ncols + 1));
+  HIPCHK(sortKeys(e->d_records.p, n, T, e->d_obj_off.p, e->d_hkeys.p, e->d_hidx.p, e->d_htmp.p, tmpBytes, s));
+  HingeArgs a;
+  a.rec = e->d_records.p; a.grads = e->d_grads.p; a.idx = e->d_hidx.p + n; a.keys = e->d_hkeys.p + n; a.n = (unsigned int)n;
+  a.B = B; a.T = T; a.K = K; a.gap = gap; a.pen_disc = dist_pen_discrete; a.pen_cast = dist_pen_cast;
+  a.rhs = e->d_hrhs.p; a.dist = e->d_hdist.p; a.wa = e->d_hwa.p; a.wb = e->d_hwb.p; a.row_t = e->d_hrowt.p; a.seg = e->d_hseg.p; a.row_off = e->d_hrowoff.p;
+  a.colcnt = e->d_hcnt.p; a.col_off = e->d_hcoloff.p; a.col_idx = e->d_hcolidx.p; a.col_val = e->d_hval.p;
+  if (n > 0) hipLaunchKernelGGL(k_hinge_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_hinge_seg, dim3((unsigned)((nseg + 1 + 255) / 256)), dim3(256), 0, s, a);
+  const bool wide = K > TOHC_HINGE_MAXK;
+  if (wide) hipLaunchKernelGGL((k_hinge_cols_wide<false>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_hinge_cols<false>), dim3((unsigned)(B * T)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_hinge_scan, dim3(1), dim3(1024), 0, s, (const unsigned int *)e->d_hcnt.p, (unsigned int)ncols, e->d_hcoloff.p);
+  if (wide) hipLaunchKernelGGL((k_hinge_cols_wide<true>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_hinge_cols<true>), dim3((unsigned)(B * T)), dim3(256), 0, s, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(e->ev_slab_read, s));
+  e->slab_read_pending = true;
+  if (n > 0) {
+    HIPCHK(hipMemcpyAsync(h.rhs.p, e->d_hrhs.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h.dist.p, e->d_hdist.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h.row_t.p, e->d_hrowt.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(hipMemcpyAsync(h.row_off.p, e->d_hrowoff.p, ((size_t)B + 1) * sizeof(long long), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(h.col_off.p, e->d_hcoloff.p, (ncols + 1) * sizeof(long long), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipEventRecord(e->ev_hinge_small, s));
+  e->hinge_open = true;
+  return TOHC_OK;
+}
+
+int tohc_fetch_hinges_end(tohc_engine *e, tohc_hinges *out) {
+  if (!e) return TOHC_E_INVALID;
+  if (!out) return fail(e, TOHC_E_INVALID, "fetch_hinges_end: null result pointer");
+  memset(out, 0, sizeof *out);
+  if (!e->hinge_open) return fail(e, TOHC_E_STATE, "fetch_hinges_end: no begin is outstanding");
+  HIPCHK(hipSetDevice(e->device));
+  e->hinge_open = false;
+  tohc_engine::HingeHost &h = e->hh[e->hinge_cur];
+  e->hinge_cur ^= 1;
+  HIPCHK(hipEventSynchronize(e->ev_hinge_small));
+  const size_t ncols = (size_t)h.B * h.T * h.K;
+  const size_t nnz = (size_t)h.col_off.p[ncols];
+  if (nnz > e->d_hval.cap) return fail(e, TOHC_E_HIP, "fetch_hinges_end: inconsistent column offsets");
+  HIPCHK(h.idx.reserve(nnz)); HIPCHK(h.val.reserve(nnz));
+  if (nnz > 0) {   // the bulk of the bytes: called after the next linearization was enqueued, this runs beside its kernels
+    HIPCHK(hipMemcpyAsync(h.idx.p, e->d_hcolidx.p, nnz * sizeof(int32_t), hipMemcpyDeviceToHost, e->hinge_stream));
+    HIPCHK(hipMemcpyAsync(h.val.p, e->d_hval.p, nnz * sizeof(double), hipMemcpyDeviceToHost, e->hinge_stream));
+  }
+  HIPCHK(hipStreamSynchronize(e->hinge_stream));
+  out->n_problems = h.B; out->T = h.T; out->K = h.K; out->gap = h.gap;
+  out->n_rows = (int64_t)h.n; out->nnz = (int64_t)nnz;
+  out->row_off = reinterpret_cast<const int64_t *>(h.row_off.p); out->rhs = h.rhs.p; out->dist = h.dist.p; out->row_t = h.row_t.p;
+  out->col_off = reinterpret_cast<const int64_t *>(h.col_off.p); out->col_idx = h.idx.p; out->col_val = h.val.p;
+  return TOHC_OK;
+}
+
+int tohc_fetch_hinges(tohc_engine *e, double dist_pen_discrete, double dist_pen_cast, tohc_hinges *out) {
+  int rc = tohc_fetch_hinges_begin(e, dist_pen_discrete, dist_pen_cast);
+  if (rc == TOHC_OK) rc = tohc_fetch_hinges_end(e, out);
+  return rc;
 }
 
 int tohc_links_vs_all_batch(tohc_engine *e, const double *dofs, int B, int T, int filter_mask, int want_jacobians, const tohc_record **records,

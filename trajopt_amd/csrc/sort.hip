@@ -45,13 +45,19 @@ hipError_t sortTempBytes(size_t n, size_t *bytes) {
                                    n, 0, 64, (hipStream_t)0);
 }
 
+hipError_t sortKeys(const tohc_record *records, size_t n, int T, const int *obj_off, uint64_t *keys, uint32_t *idx, void *tmp, size_t tmpBytes, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const unsigned int nn = (unsigned int)n;
+  hipLaunchKernelGGL(k_sort_keys, dim3((nn + 255) / 256), dim3(256), 0, s, records, nn, T, obj_off, keys, idx);
+  return rocprim::radix_sort_pairs(tmp, tmpBytes, (const uint64_t *)keys, keys + n, (const uint32_t *)idx, idx + n, n, 0, 64, s);
+}
+
 hipError_t sortRecords(const tohc_record *records, const double *grads, size_t n, int T, int K, const int *obj_off, uint64_t *keys, uint32_t *idx, void *tmp,
                        size_t tmpBytes, tohc_record *out_records, double *out_grads, hipStream_t s) {
   static_assert(sizeof(tohc_record) % 8 == 0, "records are copied as 8-byte words");
   if (n == 0) return hipSuccess;
   const unsigned int nn = (unsigned int)n;
-  hipLaunchKernelGGL(k_sort_keys, dim3((nn + 255) / 256), dim3(256), 0, s, records, nn, T, obj_off, keys, idx);
-  hipError_t e = rocprim::radix_sort_pairs(tmp, tmpBytes, (const uint64_t *)keys, keys + n, (const uint32_t *)idx, idx + n, n, 0, 64, s);
+  hipError_t e = sortKeys(records, n, T, obj_off, keys, idx, tmp, tmpBytes, s);
   if (e != hipSuccess) return e;
   const int wordsRec = (int)(sizeof(tohc_record) / 8), wordsGrad = grads ? 2 * K : 0;
   const size_t total = n * (size_t)(wordsRec + wordsGrad);

@@ -13,6 +13,9 @@ enum { SORT_MAX_SETS = 1 << 21, SORT_MAX_CHILDREN = 1 << 21 };
 
 // bytes of temporary storage sortRecords needs for n records
 hipError_t sortTempBytes(size_t n, size_t *bytes);
+// keys / idx only, no gather: afterwards keys + n holds the sorted keys and idx + n the slab position of every canonical
+// position (what the hinge assembly reads through, tohc_hinge.h)
+hipError_t sortKeys(const tohc_record *records, size_t n, int T, const int *obj_off, uint64_t *keys, uint32_t *idx, void *tmp, size_t tmpBytes, hipStream_t s);
 // order: (problem, t, cctype != 0, idA, childA, idB, childB) ascending -- the order tohc_fetch documents.
 // obj_off[object] = scene-wide number of its first child (device pointer; must ascend with the object id).
 // keys/idx: 2*n each (double buffers).  Writes records[idx[i]] -> out_records[i] and, when grads != null, the 2K

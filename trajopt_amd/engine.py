@@ -29,6 +29,15 @@ class Counters(C.Structure):
                 ("cum_gjk_iters", C.c_int64), ("cum_pen_supports", C.c_int64), ("cum_epa_supports", C.c_int64)]
 
 
+class Hinges(C.Structure):   # tohc_hinges
+    _fields_ = [("n_problems", C.c_int32), ("T", C.c_int32), ("K", C.c_int32), ("gap", C.c_int32), ("n_rows", C.c_int64), ("nnz", C.c_int64),
+                ("row_off", C.POINTER(C.c_int64)), ("rhs", C.POINTER(C.c_double)), ("dist", C.POINTER(C.c_double)), ("row_t", C.POINTER(C.c_int32)),
+                ("col_off", C.POINTER(C.c_int64)), ("col_idx", C.POINTER(C.c_int32)), ("col_val", C.POINTER(C.c_double))]
+
+
+HINGE_CAST = 1 << 30
+
+
 class EngineError(RuntimeError):
     """The reference throws std::runtime_error (collision_checker.hpp:57-62); the C-ABI returns codes."""
 
@@ -62,6 +71,9 @@ SYMBOLS = {
     "tohc_sync": (C.c_int, [C.c_void_p]),
     "tohc_fetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(_f64p), C.POINTER(C.c_int)]),
     "tohc_fetch_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "tohc_fetch_hinges": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.POINTER(Hinges)]),
+    "tohc_fetch_hinges_begin": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
+    "tohc_fetch_hinges_end": (C.c_int, [C.c_void_p, C.POINTER(Hinges)]),
     "tohc_links_vs_all_poses": (C.c_int, [C.c_void_p, _f64p, C.c_int, _i32p, C.c_int, C.c_int, C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_int)]),
     "tohc_cast_vs_all_poses": (C.c_int, [C.c_void_p, _f64p, _f64p, C.c_int, _i32p, C.c_int, C.POINTER(C.c_void_p),
@@ -209,6 +221,32 @@ class Engine:
         rec, g, n = C.c_void_p(), _f64p(), C.c_int()
         self._chk(self.lib.tohc_fetch(self.h, C.byref(rec), C.byref(g), C.byref(n)))
         return self._collect(rec, g, n, self.K, copy)
+
+    @staticmethod
+    def _hinges(h, copy):
+        """tohc_hinges -> dict of numpy arrays (views of the engine's pinned block unless copy)"""
+        ncols = h.n_problems * h.T * h.K
+        def arr(p, n, dt):
+            a = np.ctypeslib.as_array(p, shape=(n,)) if n > 0 else np.zeros(0, dt)
+            return a.copy() if copy else a
+        return dict(B=h.n_problems, T=h.T, K=h.K, gap=h.gap, n_rows=int(h.n_rows), nnz=int(h.nnz),
+                    row_off=arr(h.row_off, h.n_problems + 1, np.int64), rhs=arr(h.rhs, h.n_rows, np.float64), dist=arr(h.dist, h.n_rows, np.float64),
+                    row_t=arr(h.row_t, h.n_rows, np.int32), col_off=arr(h.col_off, ncols + 1, np.int64), col_idx=arr(h.col_idx, h.nnz, np.int32),
+                    col_val=arr(h.col_val, h.nnz, np.float64))
+
+    def fetch_hinges(self, dist_pen_discrete, dist_pen_cast=None, copy=True):
+        """The collision hinges of the enqueued linearization in BPMPD's column layout (include/trajopt_hipcc.h: tohc_hinges)."""
+        h = Hinges()
+        self._chk(self.lib.tohc_fetch_hinges(self.h, float(dist_pen_discrete), float(dist_pen_discrete if dist_pen_cast is None else dist_pen_cast), C.byref(h)))
+        return self._hinges(h, copy)
+
+    def fetch_hinges_begin(self, dist_pen_discrete, dist_pen_cast=None):
+        self._chk(self.lib.tohc_fetch_hinges_begin(self.h, float(dist_pen_discrete), float(dist_pen_discrete if dist_pen_cast is None else dist_pen_cast)))
+
+    def fetch_hinges_end(self, copy=True):
+        h = Hinges()
+        self._chk(self.lib.tohc_fetch_hinges_end(self.h, C.byref(h)))
+        return self._hinges(h, copy)
 
     def fetch_device(self):
         """-> (device address of the records, device address of the gradient rows or 0, n, doubles per gradient row)"""
