@@ -349,6 +349,54 @@ static void test_linearize(const string& in, const string& out) {
       EXPECT_TRUE(a.constant == b.constant && a.coeffs == b.coeffs);
     }
   }
+  // the same hinges as the device assembles them (tohc_fetch_hinges on the slab the prefetch left) against
+  // what sco would hand BPMPD for the reference's cost objects: ConvexObjective::addHinge (modeling.cpp:22-29: row
+  // `viol - h <= 0`) -> BPMPDModel::optimize (bpmpd_interface.cpp:352-369: rhs = -constant; per variable the (row, value)
+  // list through simplify2, solver_interface.cpp:23-37: exact zeros dropped, rows ascending).  Bit for bit.
+  {
+    tohc_hinges H;
+    EXPECT_EQ(tohc_fetch_hinges(hip->GetEngine(), W.dist_pen, W.dist_pen, &H), (int)TOHC_OK);
+    EXPECT_EQ((int)H.n_problems, 1);
+    EXPECT_EQ((int)H.T, T);
+    EXPECT_EQ((int)H.K, K);
+    // rows of the device block are in canonical order: (t, discrete before cast); the costs come discrete t = 0.., then cast
+    size_t nrows = 0;
+    for (auto& c : B.convex) nrows += c->hinges.size();
+    EXPECT_EQ((size_t)H.n_rows, nrows);
+    vector<int> rowOfHinge;   // device row of the h-th hinge in cost order
+    {
+      vector<vector<int> > rowsOf(2 * T);   // [t] discrete, [T + t] cast
+      for (int i = 0; i < (int)H.n_rows; ++i) rowsOf[(H.row_t[i] & TOHC_HINGE_CAST) ? T + (H.row_t[i] & ~TOHC_HINGE_CAST) : H.row_t[i]].push_back(i);
+      for (size_t ci = 0; ci < B.convex.size(); ++ci) {
+        EXPECT_EQ(rowsOf[ci].size(), B.convex[ci]->hinges.size());
+        for (int r : rowsOf[ci]) rowOfHinge.push_back(r);
+      }
+    }
+    if ((size_t)H.n_rows == nrows && rowOfHinge.size() == nrows) {
+      std::map<int, std::map<int, double> > var2cnt;   // var -> (row -> value), what simplify2 leaves
+      size_t h = 0;
+      for (auto& c : B.convex)
+        for (auto& hg : c->hinges) {
+          const AffExpr& aff = hg.first;
+          const int row = rowOfHinge[h++];
+          EXPECT_TRUE(H.rhs[row] == -aff.constant);
+          for (size_t j = 0; j < aff.coeffs.size(); ++j)
+            if (aff.coeffs[j] != 0) var2cnt[aff.vars[j].var_index][row] += aff.coeffs[j];
+        }
+      size_t nnz = 0;
+      for (int v = 0; v < T * K; ++v) {
+        const std::map<int, double>& col = var2cnt[v];
+        EXPECT_EQ((size_t)(H.col_off[v + 1] - H.col_off[v]), col.size());
+        size_t e = (size_t)H.col_off[v];
+        for (auto& rv : col) {
+          if (e < (size_t)H.col_off[v + 1]) EXPECT_TRUE(H.col_idx[e] == rv.first && H.col_val[e] == rv.second);
+          ++e, ++nnz;
+        }
+      }
+      EXPECT_EQ((size_t)H.nnz, nnz);
+      EXPECT_TRUE(nnz > 0);
+    }
+  }
   // IgnoreZeroStateSelfCollisions() once more, now with a configuration bound (collision_checker.cpp:58-66): the robot is
   // lifted to z = 10 by SetTransform, which the bound DOF vector cannot express -- nothing may change
   // (not with a grabbed body: it is carried along to z = 10, so the call -- rightly -- finds and excludes its contacts
