@@ -83,6 +83,9 @@ typedef struct tohc_counters {
    * Distance fall-back in k_pen; EPA iterations and EncloseOrigin in k_epa).  Since the last sync / cumulative. */
   int64_t gjk_iters, pen_supports, epa_supports;
   int64_t cum_gjk_iters, cum_pen_supports, cum_epa_supports;
+  /* EPA runs that left the small first-attempt pools of k_tail_epa and were repeated on the reference's full pools
+   * (64 support vertices, 128 faces): same results either way, this only says how often the short cut missed */
+  int64_t epa_redone, cum_epa_redone;
 } tohc_counters;
 
 /* replaces CreateCollisionChecker(env)                       src/trajopt/bullet_collision_checker.cpp:1036-1039 */

@@ -36,6 +36,7 @@ void load(const World *w, int child, Cvx<1> &c) {
 Xf childWorld(const World *w, int obj, int c, const Xf &T) { return w->compound[obj] ? xfMul(T, w->child_T[w->off[obj] + c]) : T; }
 long g_iter_hist[64];
 long g_epa_hist[2];
+long g_epa_redone;
 long g_pre[8];
 bool pairEval(World *w, const Cvx<1> &A, const Xf &tA, const Cvx<1> &B, const Xf &tB, ora_contact *c) {
   const float md = pairMaxDist2<1>(A, B, w->breaking);
@@ -78,9 +79,16 @@ bool pairEval(World *w, const Cvx<1> &A, const Xf &tA, const Cvx<1> &B, const Xf
     if (penStage1<1, G2Mem>(&mem2, A, B, lA, lB, g1, isValid2, sep, tmpA, tmpB)) {
       PenHand h;
       penSave<1, G2Mem>(h, g1);
-      Gjk2<1, EpaMem> g2;
-      penRestore<1>(&mem, h, A, B, lA, lB, g2);
-      penStage2<1>(&mem, lA, lB, g2, isValid2, sep, tmpA, tmpB);
+      // k_tail_epa: first on the small pools, again on the reference's full ones when the run would leave them
+      static EpaMemS memS;
+      Gjk2<1, EpaMemS> gs;
+      penRestore<1>(&memS, h, A, B, lA, lB, gs);
+      if (!penStage2<1>(&memS, lA, lB, gs, isValid2, sep, tmpA, tmpB)) {
+        g_epa_redone++;
+        Gjk2<1, EpaMem> g2;
+        penRestore<1>(&mem, h, A, B, lA, lB, g2);
+        penStage2<1>(&mem, lA, lB, g2, isValid2, sep, tmpA, tmpB);
+      }
     }
     gjkFinishTail(isValid2, sep, tmpA, tmpB, st);
   }
@@ -350,5 +358,6 @@ long emu_stat(int i) {
 }
 long emu_pre(int i) { return g_pre[i]; }
 long emu_iter_hist(int i) { return g_iter_hist[i]; }
+long emu_epa_redone() { return g_epa_redone; }
 long emu_counter(void *h, int which) { World *w = (World *)h; return which == 0 ? w->pair_evals : w->epa_evals; }
 }

@@ -2,7 +2,8 @@
 host / fall-back paths agree with the oracle.
 
   * engine variants (environment switches read by tohc_create): pre-test off, one stream, enqueues cut into unit
-    ranges on four lanes, host-side canonical sort, 16-lane-group GJK, one EPA group per wavefront, two passes sharing one penetration tail;
+    ranges on four lanes, host-side canonical sort, 16-lane-group GJK, one EPA group per wavefront, two passes sharing one penetration tail,
+    EPA runs repeated on the full pools;
   * several appended enqueues in one slab (the lanes' ordering events);
   * a robot with two joints on one optimisation column (mimic joint): k_finish's lane-per-column fall-back.
 """
@@ -18,7 +19,8 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 VARIANTS = [{}, {"TOHC_PRETEST": "0"}, {"TOHC_STREAMS": "1"}, {"TOHC_CHUNKS": "2", "TOHC_STREAMS": "4"}, {"TOHC_HOST_SORT": "1"},
-            {"TOHC_GJK_GROUP": "16"}, {"TOHC_EPA_BLOCK": "16"}, {"TOHC_GROUP": "64"}, {"TOHC_MERGE_TAIL": "1"}]
+            {"TOHC_GJK_GROUP": "16"}, {"TOHC_EPA_BLOCK": "16"}, {"TOHC_GROUP": "64"}, {"TOHC_MERGE_TAIL": "1"},
+            {"TOHC_EPA_SMALL": "5,10"}]   # EPA's first-attempt pools so small that most runs are repeated on the full pools
 
 
 def _world():
@@ -85,6 +87,8 @@ def test_engine_variants_compute_the_same_slab(built):
         assert c["pair_evals"] == ref_c["pair_evals"] and c["contacts"] == ref_c["contacts"], tag
         if env.get("TOHC_PRETEST") == "0":
             assert c["gjk_evals"] == c["pair_evals"]
+        if "TOHC_EPA_SMALL" in env:
+            assert c["epa_redone"] > 0.05 * c["epa_evals"] > 0, (c["epa_redone"], c["epa_evals"])
     # and the slab is right: one problem against the oracle, pass by pass
     w = B.oracle_world(s, cap=1 << 17)
     w.set_contact_distance(0.09)

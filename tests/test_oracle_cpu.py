@@ -8,6 +8,7 @@
   * FK / Jacobian: finite differences + closed-form planar arm (OpenRAVE parity is UNPINNED, SURVEY.md 8c);
   * libtrajopt_hipcc.so loads and exports every symbol of include/trajopt_hipcc.h; no compute without a GPU.
 """
+import ctypes as C
 import glob
 import os
 import re
@@ -217,6 +218,36 @@ def test_oracle_vs_reference_bullet_random(built, seed):
         util.assert_same_contacts(we.cast_vs_all(objT, robot, objT[robot], T1), refc, "emu cast")
     for w in (wr, wo, we):
         w.close()
+
+
+def test_epa_small_pools_then_full_pools_same_results(built, tmp_path):
+    """k_tail_epa runs EPA on small pools first and repeats a run that leaves them on the reference's pools.  Here the
+    host build of the device source is compiled with pools so small (6 support vertices, 10 faces) that most runs are
+    repeated, on crowded scenes (deep penetrations): contact sets and values equal the oracle's (and the reference's
+    Bullet where it is built) bit for bit -- the short cut is invisible."""
+    import subprocess
+    lib = str(tmp_path / "libemu_tiny.so")
+    subprocess.run(["g++", "-O2", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wno-unknown-pragmas", "-DTOHC_EPA_SMALL_V=6",
+                    "-DTOHC_EPA_SMALL_F=10", "-shared", "-o", lib, os.path.join(util.ROOT, "tests", "emu", "emu.cpp")], check=True)
+    dll = C.CDLL(lib)
+    dll.emu_epa_redone.restype = C.c_long
+    dll.emu_counter.restype = C.c_long
+    for seed in (101, 303, 905):
+        rng = np.random.default_rng(seed)
+        s, objT, robot = synth.random_scene(rng, spread=0.3, round_prob=0.5 if seed >= 300 else 0.0, spheres=seed >= 900, n_static=10, n_robot=6)
+        worlds = [B.oracle_world(s), B.World(dll, "emu_", s)] + ([B.ref_world(s)] if B.ref_available() else [])
+        T1 = objT[robot].copy()
+        T1[:, 4:] += rng.normal(size=(len(robot), 3)) * 0.15
+        for w in worlds:
+            w.set_contact_distance(0.09)
+        res = [(w.links_vs_all(objT, robot), w.cast_vs_all(objT, robot, objT[robot], T1)) for w in worlds]
+        for r in res[1:]:
+            util.assert_same_contacts(r[0], res[0][0], "disc")
+            util.assert_same_contacts(r[1], res[0][1], "cast")
+        assert (res[0][0]["dist"] < -0.01).any()
+        for w in worlds:
+            w.close()
+    assert dll.emu_epa_redone() > 20, dll.emu_epa_redone()
 
 
 @pytest.mark.parametrize("mk", WORLDS)

@@ -206,6 +206,7 @@ struct tohc_engine {
   int gjk_group = 1;  // lanes per pair in k_gjk: 1 (default), 16 or 64 (TOHC_GJK_GROUP)
   int pen_group = 1;   // lanes per pair in k_pen: 1, or 4 (hull vertices in registers; TOHC_PEN_GROUP=4: measured no faster, GJK2's LDS bookkeeping dominates)
   int epa_block = 64;  // threads per k_epa block (TOHC_EPA_BLOCK = 16 or 64)
+  unsigned int epa_small_v = TOHC_EPA_SMALL_V, epa_small_f = TOHC_EPA_SMALL_F;   // TOHC_EPA_SMALL=v,f shrinks k_tail_epa's first-attempt pools (tests of the repeat path)
   int pretest = 1;   // TOHC_PRETEST=0 turns the separating-axis pre-test off (A/B measurements)
   tohc_engine() { memset(&counters, 0, sizeof counters); }
 };
@@ -331,6 +332,10 @@ int tohc_create(tohc_engine **out, int device) {
   }
   if (const char *mt = getenv("TOHC_MERGE_TAIL")) e->max_open = atoi(mt) != 0 ? TOHC_MAX_HEADS : 1;
   if (const char *eb = getenv("TOHC_EPA_BLOCK")) e->epa_block = atoi(eb) == 16 ? 16 : 64;
+  if (const char *es = getenv("TOHC_EPA_SMALL")) {
+    unsigned int v = 0, f = 0;
+    if (sscanf(es, "%u,%u", &v, &f) == 2 && v >= 1 && f >= 4) { e->epa_small_v = std::min(v, (unsigned int)TOHC_EPA_SMALL_V); e->epa_small_f = std::min(f, (unsigned int)TOHC_EPA_SMALL_F); }
+  }
   if (const char *pg = getenv("TOHC_PEN_GROUP")) e->pen_group = atoi(pg) == 4 ? 4 : 1;
   if (const char *hs = getenv("TOHC_HOST_SORT")) e->host_sort = atoi(hs) != 0;
   e->gjk_group = e->group == 64 ? 64 : 1;
@@ -834,22 +839,23 @@ static int syncEngineImpl(tohc_engine *e) {
   unsigned int worst_pairs = 0;
   tohc_counters &c = e->counters;
   c.aabb_tests = c.pair_evals = c.epa_evals = c.gjk_evals = 0;
-  c.gjk_iters = c.pen_supports = c.epa_supports = 0;
+  c.gjk_iters = c.pen_supports = c.epa_supports = c.epa_redone = 0;
   c.ms_last_call = 0;
   for (const auto &pd : e->pending) {
     const Counters &k = e->h_cnt.p[pd.slot];
     const unsigned int segCap = (unsigned int)(e->max_pairs / TOHC_NSHARD);
     unsigned int np = 0, ne = 0, ng = 0;
-    int64_t gi = 0, ps = 0, es = 0;
+    int64_t gi = 0, ps = 0, es = 0, er = 0;
     overflow |= k.overflow != 0;
     for (int sh = 0; sh < TOHC_NSHARD; ++sh) {
       const CounterShard &cs = k.sh[sh];
       overflow |= cs.n_pairs > segCap || cs.n_epa > segCap || cs.n_hits > segCap || cs.n_pen > segCap / TOHC_PEN_DIV;
       np += cs.n_cand; ng += cs.n_pairs; ne += cs.n_epa;
-      gi += cs.n_gjk_steps; ps += cs.n_pen_sups; es += cs.n_epa_sups;
+      gi += cs.n_gjk_steps; ps += cs.n_pen_sups; es += cs.n_epa_sups; er += cs.n_epa_redone;
     }
     c.gjk_iters += gi; c.pen_supports += ps; c.epa_supports += es;
     c.cum_gjk_iters += gi; c.cum_pen_supports += ps; c.cum_epa_supports += es;
+    c.epa_redone += er; c.cum_epa_redone += er;
     worst_pairs = std::max(worst_pairs, ng);
     c.aabb_tests += pd.aabb_tests; c.pair_evals += np; c.epa_evals += ne; c.gjk_evals += ng;
     c.cum_aabb_tests += pd.aabb_tests; c.cum_pair_evals += np; c.cum_epa_evals += ne; c.cum_gjk_evals += ng;
@@ -867,12 +873,17 @@ static int syncEngineImpl(tohc_engine *e) {
   }
 #if defined(TOHC_EPA_PROF)
   if (e->d_dbg.p) {
-    unsigned long long h[32];
+    unsigned long long h[160];
     HIPCHK(hipMemcpy(h, e->d_dbg.p, sizeof h, hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(e->d_dbg.p, 0, sizeof h));
     if (h[0]) {
       fprintf(stderr, "[epa prof] evals %llu  mean wall %.2f us  max wall %.2f us  mean cycles %.0f\n", h[0], h[1] / (double)h[0] / 100.0, h[3] / 100.0, h[2] / (double)h[0]);
       const char *nm[8] = {"init", "support", "expand(x3)", "findbest", "enclose", "newface x4", "evaluate", "-"};
+      fprintf(stderr, "   support vertices added (histogram 0..63):");
+      for (int k = 0; k < 64; ++k) fprintf(stderr, " %llu", h[32 + k]);
+      fprintf(stderr, "\n   highest face slot used / 2 (histogram 0..63):");
+      for (int k = 0; k < 64; ++k) fprintf(stderr, " %llu", h[96 + k]);
+      fprintf(stderr, "\n");
       for (int k = 0; k < 7; ++k) fprintf(stderr, "   %-12s calls/eval %.2f  cycles/eval %.0f  cycles/call %.0f\n", nm[k], h[16 + k] / (double)h[0], h[8 + k] / (double)h[0], h[16 + k] ? h[8 + k] / (double)h[16 + k] : 0.0);
     }
   }
@@ -917,6 +928,9 @@ static int64_t countAabbTests(const tohc_engine *e, const std::vector<int> &qchi
 #ifndef TOHC_EPA_GRID
 #define TOHC_EPA_GRID 2048
 #endif
+#ifndef TOHC_EPA_G
+#define TOHC_EPA_G 8   // lanes per pair in k_tail_epa (8 pairs per wavefront on the small pools: measured 0.45 ms per launch against 0.67 for 16 lanes on the full pools)
+#endif
 #ifndef TOHC_FINISH_BLOCKS_PER_CU
 #define TOHC_FINISH_BLOCKS_PER_CU 4   // with TOHC_FINISH_WAVES 4 (128 VGPRs): four waves per SIMD = 4 blocks of 256 per CU (measured: 2 -> 3 blocks +5 %, 4 / 4 another +3 %)
 #endif
@@ -956,13 +970,13 @@ static int launchTail(tohc_engine *e) {
       else hipLaunchKernelGGL((k_tail_pen<1, 1, 0>), dim3(gridN), dim3(64), 0, ts, ta);
       if (e->group == 64) hipLaunchKernelGGL((k_tail_epa<64, 64, 1>), dim3(gridN), dim3(64), 0, ts, ta);
       else if (e->epa_block == 16) hipLaunchKernelGGL((k_tail_epa<16, 16, 1>), dim3(gridN * 4), dim3(16), 0, ts, ta);  // one group per wavefront
-      else hipLaunchKernelGGL((k_tail_epa<16, 64, 1>), dim3(TOHC_EPA_GRID), dim3(64), 0, ts, ta);
+      else hipLaunchKernelGGL((k_tail_epa<TOHC_EPA_G, 64, 1>), dim3(TOHC_EPA_GRID), dim3(64), 0, ts, ta);
     } else {   // nh == TOHC_MAX_HEADS == 2
       if (e->pen_group == 4) hipLaunchKernelGGL((k_tail_pen<4, 2, 2>), dim3(gridN * 2), dim3(64), 0, ts, ta);
       else hipLaunchKernelGGL((k_tail_pen<1, 2, 2>), dim3(gridN * 2), dim3(64), 0, ts, ta);
       if (e->group == 64) hipLaunchKernelGGL((k_tail_epa<64, 64, 2>), dim3(gridN * 2), dim3(64), 0, ts, ta);
       else if (e->epa_block == 16) hipLaunchKernelGGL((k_tail_epa<16, 16, 2>), dim3(gridN * 4 * 2), dim3(16), 0, ts, ta);
-      else hipLaunchKernelGGL((k_tail_epa<16, 64, 2>), dim3(TOHC_EPA_GRID * 2), dim3(64), 0, ts, ta);
+      else hipLaunchKernelGGL((k_tail_epa<TOHC_EPA_G, 64, 2>), dim3(TOHC_EPA_GRID * 2), dim3(64), 0, ts, ta);
     }
   }
   // A hinge assembly may still be reading the previous slab (tohc_fetch_hinges_begin): the broadphase, GJK and the
@@ -1026,11 +1040,12 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
   if (!append) HIPCHK(hipMemsetAsync(e->d_nrec.p, 0, sizeof(unsigned int), s));
   cp.seg_cap = (unsigned int)(e->max_pairs / TOHC_NSHARD); cp.max_records = (unsigned int)e->max_records;
   cp.dbg_max_iter = getenv("TOHC_DBG_MAXITER") ? atoi(getenv("TOHC_DBG_MAXITER")) : 1000;
+  cp.epa_small_v = e->epa_small_v; cp.epa_small_f = e->epa_small_f;
   const size_t qcap = (size_t)cp.seg_cap * TOHC_NSHARD;
   HIPCHK(ln.pairs.reserve(qcap)); HIPCHK(ln.epaq.reserve(qcap)); HIPCHK(ln.hits.reserve(qcap));
   HIPCHK(ln.penq.reserve((size_t)(cp.seg_cap / TOHC_PEN_DIV) * TOHC_NSHARD));
 #if defined(TOHC_EPA_PROF)
-  if (!e->d_dbg.p) { HIPCHK(e->d_dbg.reserve(32)); HIPCHK(hipMemset(e->d_dbg.p, 0, 32 * sizeof(unsigned long long))); }
+  if (!e->d_dbg.p) { HIPCHK(e->d_dbg.reserve(160)); HIPCHK(hipMemset(e->d_dbg.p, 0, 160 * sizeof(unsigned long long))); }
 #endif
   HIPCHK(e->d_records.reserve(e->max_records));
   HIPCHK(e->d_grads.reserve(e->max_records * 2 * (size_t)K));
@@ -1106,6 +1121,7 @@ static int launchSweep(tohc_engine *e, const DynMap &dm, const int *d_qchildren,
   HIPCHK(hipMemsetAsync(e->d_nrec.p, 0, sizeof(unsigned int), s));
   cp.seg_cap = (unsigned int)(e->max_pairs / TOHC_NSHARD); cp.max_records = (unsigned int)e->max_records;
   cp.dbg_max_iter = 1000;
+  cp.epa_small_v = e->epa_small_v; cp.epa_small_f = e->epa_small_f;
   HIPCHK(e->d_records.reserve(e->max_records));
   HIPCHK(hipEventRecord(ev[2], s));
   if (nQ > 0 && cp.n_cast_sets > 0) {

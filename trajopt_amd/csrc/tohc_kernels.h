@@ -95,7 +95,8 @@ struct CounterShard {
   unsigned int n_gjk_steps;   // passes of the GJK loop body in k_gjk (one Minkowski support query each)
   unsigned int n_pen_sups;    // Minkowski support queries of GJK2 / the Distance fall-back in k_pen
   unsigned int n_epa_sups;    // the same in k_epa (one per EPA iteration, plus EncloseOrigin's)
-  unsigned int pad[24];
+  unsigned int n_epa_redone;  // EPA runs repeated on the full pools
+  unsigned int pad[23];
 };
 struct Counters {
   CounterShard sh[TOHC_NSHARD];
@@ -116,6 +117,7 @@ struct CallParams {
   unsigned int seg_cap;      // capacity of ONE shard of the pair / EPA / hit queues
   unsigned int max_records;
   int dbg_max_iter;          // diagnostics only: 1000 = the reference's gGjkMaxIter
+  unsigned int epa_small_v, epa_small_f;   // k_tail_epa's first-attempt pools (<= TOHC_EPA_SMALL_V / _F; smaller only in tests)
 };
 
 __host__ __device__ __forceinline__ Xf ldXf(const float *p) {
@@ -1022,13 +1024,20 @@ __global__ void __launch_bounds__(64, TOHC_PEN_WAVES) k_tail_pen(TailArgs ta) {
   waveAdd(&a.cnt->sh[blockIdx.x % TOHC_NSHARD].n_pen_sups, sups);
 }
 
-// k_tail_epa: second stage (EPA proper) for the pairs k_tail_pen handed over, one group of G lanes per pair, pools in LDS
+// k_tail_epa: second stage (EPA proper) for the pairs k_tail_pen handed over, one group of G lanes per pair, pools in LDS.
+// Every run starts on small pools (EpaMemS, 2.5 KB a group instead of 6.3 KB: eight groups per wavefront at the
+// occupancy the registers allow); a run that would leave them is repeated from the hand-over on the reference's full
+// pools, which lie over the block's small ones -- the groups of the wavefront that need it take turns once all small
+// runs of the round have ended.
 template <int G, int BLOCK, int NH>
 __global__ void __launch_bounds__(BLOCK, TOHC_EPA_WAVES) k_tail_epa(TailArgs ta) {
-  __shared__ EpaMem mem[BLOCK / G];
-  const int groupsPerBlock = BLOCK / G;
-  EpaMem *m = &mem[threadIdx.x / G];
-  unsigned int sups = 0;
+  static_assert(BLOCK <= 64, "the groups of a block take turns on one full pool: one wavefront per block");
+  constexpr int groupsPerBlock = BLOCK / G;
+  constexpr size_t ldsBytes = sizeof(EpaMemS) * groupsPerBlock > sizeof(EpaMem) ? sizeof(EpaMemS) * groupsPerBlock : sizeof(EpaMem);
+  __shared__ __align__(16) unsigned char lds[ldsBytes];
+  EpaMemS *ms = reinterpret_cast<EpaMemS *>(lds) + threadIdx.x / G;
+  EpaMem *mb = reinterpret_cast<EpaMem *>(lds);
+  unsigned int sups = 0, redone = 0;
   for (int hh = 0; hh < NH; ++hh) {   // the block's own head first, then whatever the others still hold
     const int head = NH == 1 ? 0 : (int)((blockIdx.x + (unsigned int)hh) % (unsigned int)NH);
     const NarrowArgs &a = ta.h[head];
@@ -1036,8 +1045,6 @@ __global__ void __launch_bounds__(BLOCK, TOHC_EPA_WAVES) k_tail_epa(TailArgs ta)
     QPrefix pre;
     qprefix(&a.cnt->sh[0].n_pen, cap2, pre);
     const unsigned int npen = pre.start[TOHC_NSHARD];
-    float md2 = a.cp.breaking;
-    md2 *= md2;
     // Pairs are handed out on demand, BLOCK / G at a time per wavefront (a block is one wavefront or less): EPA runs take
     // from 2 to 255 iterations, and with a fixed share per group the kernel lasted as long as its unluckiest group.
     for (;;) {
@@ -1046,42 +1053,65 @@ __global__ void __launch_bounds__(BLOCK, TOHC_EPA_WAVES) k_tail_epa(TailArgs ta)
       first = __shfl(first, 0);
       if (first >= npen) break;
       const unsigned int i = first + threadIdx.x / G;
-      if (i >= npen) continue;
-      const PenRec *r = &a.penq[qlocate(pre, cap2, i)];
+      const bool mine = i < npen;
+      const PenRec *r = &a.penq[qlocate(pre, cap2, mine ? i : first)];
       const EpaRec e = r->e;
       Cvx<G> A, B;
       Xf tA, tB, lA, lB;
       GjkState st;
       loadQueued<G>(a, e, a.cp.cast != 0, A, B, tA, tB, st);
-      md2 = pairMaxDist2<G>(A, B, a.cp.breaking);
+      const float md2 = pairMaxDist2<G>(A, B, a.cp.breaking);
       penLocal(tA, tB, st.offset, lA, lB);
-      Gjk2<G, EpaMem> g;
-      penRestore<G>(m, r->h, A, B, lA, lB, g);
       V3 tmpA = mk(0, 0, 0), tmpB = mk(0, 0, 0), sep = mk(0, 0, 0);
       bool isValid2 = false;
+      bool ok = true;
+      unsigned int nsup = 0;
+      if (mine) {
+        Gjk2<G, EpaMemS> g;
+        penRestore<G>(ms, r->h, A, B, lA, lB, g);
 #if defined(TOHC_EPA_PROF)
-      const unsigned long long tw0 = wall_clock64(), tc0 = clock64();
-      EpaProf prof;
-      penStage2<G>(m, lA, lB, g, isValid2, sep, tmpA, tmpB, &prof);
-      if (Grp<G>::lane() == 0 && a.dbg) {
-        atomicAdd(&a.dbg[0], 1ull);
-        atomicAdd(&a.dbg[1], wall_clock64() - tw0);
-        atomicAdd(&a.dbg[2], clock64() - tc0);
-        atomicMax(&a.dbg[3], wall_clock64() - tw0);
-        for (int k = 0; k < 8; ++k) { atomicAdd(&a.dbg[8 + k], prof.t[k]); atomicAdd(&a.dbg[16 + k], (unsigned long long)prof.n[k]); }
-      }
+        const unsigned long long tw0 = wall_clock64(), tc0 = clock64();
+        EpaProf prof;
+        ok = penStage2<G>(ms, lA, lB, g, isValid2, sep, tmpA, tmpB, &prof, a.cp.epa_small_v, a.cp.epa_small_f);
+        if (Grp<G>::lane() == 0 && a.dbg) {
+          atomicAdd(&a.dbg[0], 1ull);
+          atomicAdd(&a.dbg[1], wall_clock64() - tw0);
+          atomicAdd(&a.dbg[2], clock64() - tc0);
+          atomicMax(&a.dbg[3], wall_clock64() - tw0);
+          for (int k = 0; k < 8; ++k) { atomicAdd(&a.dbg[8 + k], prof.t[k]); atomicAdd(&a.dbg[16 + k], (unsigned long long)prof.n[k]); }
+          atomicAdd(&a.dbg[32 + (prof.nsv < 63 ? prof.nsv : 63)], 1ull);
+          atomicAdd(&a.dbg[96 + (prof.maxface < 127 ? prof.maxface : 127) / 2], 1ull);
+        }
 #else
-      penStage2<G>(m, lA, lB, g, isValid2, sep, tmpA, tmpB);
+        ok = penStage2<G>(ms, lA, lB, g, isValid2, sep, tmpA, tmpB, nullptr, a.cp.epa_small_v, a.cp.epa_small_f);
 #endif
-      gjkFinishTail(isValid2, sep, tmpA, tmpB, st);
-      pushIfContact<G>(a, (unsigned int)e.pair, st, md2);
-      if (Grp<G>::lane() == 0) sups += g.nsup;
+        nsup = g.nsup;
+      }
+      // (every lane of the wavefront is here again: no small pool is in use any more)
+      unsigned long long redo = __ballot(!ok);
+      while (redo) {
+        const unsigned int grp = (unsigned int)__builtin_ctzll(redo) / G;
+        if (threadIdx.x / G == grp) {
+          Gjk2<G, EpaMem> g;
+          penRestore<G>(mb, r->h, A, B, lA, lB, g);
+          penStage2<G>(mb, lA, lB, g, isValid2, sep, tmpA, tmpB);
+          nsup = g.nsup;
+          ++redone;
+        }
+        redo &= ~((G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << (grp * G));
+      }
+      if (mine) {
+        gjkFinishTail(isValid2, sep, tmpA, tmpB, st);
+        pushIfContact<G>(a, (unsigned int)e.pair, st, md2);
+        if (Grp<G>::lane() == 0) sups += nsup;
+      }
     }
   }
-  // (work counter only: booked on the block's own head)
-  unsigned int *ctr = &ta.h[NH == 1 ? 0 : blockIdx.x % (unsigned int)NH].cnt->sh[blockIdx.x % TOHC_NSHARD].n_epa_sups;
-  if (BLOCK >= 64) waveAdd(ctr, sups);
-  else if (sups) atomicAdd(ctr, sups);
+  // (work counters only: booked on the block's own head)
+  CounterShard *cs = &ta.h[NH == 1 ? 0 : blockIdx.x % (unsigned int)NH].cnt->sh[blockIdx.x % TOHC_NSHARD];
+  if (Grp<G>::lane() != 0) redone = 0;
+  if (BLOCK >= 64) { waveAdd(&cs->n_epa_sups, sups); waveAdd(&cs->n_epa_redone, redone); }
+  else { if (sups) atomicAdd(&cs->n_epa_sups, sups); if (redone) atomicAdd(&cs->n_epa_redone, redone); }
 }
 
 // point Jacobian of `link` at world point p, column k: CalculateActiveJacobian as used by PositionJacobian

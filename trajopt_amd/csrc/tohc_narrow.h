@@ -645,8 +645,18 @@ TOHC_DEV void gjkMain(const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &
 // GJK2 + EPA [epa].  All pools live in EpaMem (LDS on the device), indexed by small integers instead of pointers;
 // the recursions of EncloseOrigin and expand are unrolled onto explicit stacks that visit faces in the same order.
 // ---------------------------------------------------------------------------------------------------------------
-#define TOHC_EPA_MAX_VERTICES 64
+#define TOHC_EPA_MAX_VERTICES 64   // the reference's limits (EPA_MAX_VERTICES, EPA_MAX_FACES): part of the results
 #define TOHC_EPA_MAX_FACES 128
+// The small pools k_tail_epa tries first: a run that stays inside them is, step for step, the run on the full pools
+// (the lowest free face slot is the same slot in both), and one that would leave them is started again on the full
+// ones.  Measured on config 4 (74 K runs): 99.98 % add <= 16 support vertices and none more than 24; 99.9 % never touch
+// a face slot >= 32 and one reaches slot 50.  The runs that leave the pools are the longest ones, and repeating one costs
+// its whole length again at the end of the kernel, so the pools are as large as the occupancy the registers give
+// (8 wavefronts per CU, 8 groups each: 160 KB / 64 = 2.5 KB) lets them be.
+#ifndef TOHC_EPA_SMALL_V
+#define TOHC_EPA_SMALL_V 24
+#define TOHC_EPA_SMALL_F 48
+#endif
 #define TOHC_NIL 255
 
 // One record per access: a face is read as (normal, distance) = one 16-byte load, its three vertex ids + pass mark
@@ -654,21 +664,25 @@ TOHC_DEV void gjkMain(const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &
 // trips, so what counts is how few of them a step needs, not how many bytes.  Which faces are on the hull / free is
 // kept in two 128-bit masks in registers (Epa), not in linked lists: the list order matters to the reference only in
 // findbest's tie rule, which the arrival stamp reproduces.
-struct alignas(16) EpaMem {
-  // support vertices: 0..3 = GJK2's m_store, 4..67 = EPA's m_sv_store
-  float svd[4 + TOHC_EPA_MAX_VERTICES][4];
-  float svw[4 + TOHC_EPA_MAX_VERTICES][4];
-  float fnd[TOHC_EPA_MAX_FACES][4];      // n.x n.y n.z d
-  uint32_t fcp[TOHC_EPA_MAX_FACES];      // bytes: c[0] c[1] c[2] pass
-  uint32_t ff[TOHC_EPA_MAX_FACES];       // bytes: f[0] f[1] f[2] -
-  uint32_t fe[TOHC_EPA_MAX_FACES];       // bytes: e[0] e[1] e[2] -
-  uint16_t fstamp[TOHC_EPA_MAX_FACES];   // order of arrival on the hull (the reference's hull list is newest-first)
-  uint16_t stk[TOHC_EPA_MAX_FACES];      // expand() stack: face | edge << 8 | stage << 10
+template <int NV, int NF>
+struct alignas(16) EpaMemT {
+  static constexpr int kNV = NV, kNF = NF;
+  // support vertices: 0..3 = GJK2's m_store, 4.. = EPA's m_sv_store
+  float svd[4 + NV][4];
+  float svw[4 + NV][4];
+  float fnd[NF][4];      // n.x n.y n.z d
+  uint32_t fcp[NF];      // bytes: c[0] c[1] c[2] pass
+  uint32_t ff[NF];       // bytes: f[0] f[1] f[2] -
+  uint32_t fe[NF];       // bytes: e[0] e[1] e[2] -
+  uint16_t fstamp[NF];   // order of arrival on the hull (the reference's hull list is newest-first)
+  uint16_t stk[NF];      // expand() stack: face | edge << 8 | stage << 10
   // GJK2 simplices
   uint8_t sc[2][4];
   float sp[2][4];
   uint8_t freeL[4];
 };
+typedef EpaMemT<TOHC_EPA_MAX_VERTICES, TOHC_EPA_MAX_FACES> EpaMem;   // the reference's pools
+typedef EpaMemT<TOHC_EPA_SMALL_V, TOHC_EPA_SMALL_F> EpaMemS;        // first attempt (k_tail_epa)
 
 // the part of EpaMem that GJK2 alone touches: one per LANE in the lane-per-pair penetration kernel (k_pen)
 struct G2Mem {
@@ -966,7 +980,7 @@ struct Gjk2 {
 
 // optional in-kernel profile of EPA (k_epa built with TOHC_EPA_PROF): cycle counts per phase, summed over evaluations
 #if defined(TOHC_EPA_PROF) && defined(__HIPCC__)
-struct EpaProf { unsigned long long t[8]; unsigned n[8]; };
+struct EpaProf { unsigned long long t[8]; unsigned n[8]; unsigned maxface, nsv; };
 #define TOHC_PROF_T0(x) unsigned long long x = clock64()
 #define TOHC_PROF_ACC(p, k, x) do { (p).t[k] += clock64() - (x); (p).n[k]++; } while (0)
 #else
@@ -977,10 +991,12 @@ struct EpaProf {};
 
 enum { E_VALID, E_TOUCHING, E_DEGENERATED, E_NONCONVEX, E_INVALIDHULL, E_OUTOFFACES, E_OUTOFVERTICES, E_ACCURACY, E_FALLBACK, E_FAILED };
 
-template <int G>
+template <int G, class MEM = EpaMem>
 struct Epa {
-  EpaMem *m;
+  MEM *m;
   int status;
+  bool exhausted;   // a pool smaller than the reference's ran out: the run says nothing, start again on the full pools
+  unsigned limV, limF;   // pool sizes in use (<= MEM's; smaller only in tests of the repeat path)
   unsigned rrank;
   unsigned rc[3];
   float rp[3];
@@ -1010,7 +1026,9 @@ struct Epa {
     if (f < 64) { hullLo &= ~(1ull << f); freeLo |= 1ull << f; } else { hullHi &= ~(1ull << (f - 64)); freeHi |= 1ull << (f - 64); }
     --hullCount;
   }
-  TOHC_DEV void init() {  // [epa:583-593]
+  TOHC_DEV void init(unsigned lv = MEM::kNV, unsigned lf = MEM::kNF) {  // [epa:583-593]
+    limV = lv < (unsigned)MEM::kNV ? lv : (unsigned)MEM::kNV;
+    limF = lf < (unsigned)MEM::kNF ? lf : (unsigned)MEM::kNF;
     status = E_FAILED;
     normal = mk(0, 0, 0);
     depth = 0;
@@ -1018,7 +1036,9 @@ struct Epa {
     stamp = 0;
     hullLo = hullHi = 0;
     hullCount = 0;
-    freeLo = freeHi = ~0ull;
+    freeLo = limF >= 64 ? ~0ull : (1ull << (limF & 63)) - 1ull;
+    freeHi = limF >= 128 ? ~0ull : (limF > 64 ? (1ull << (limF & 63)) - 1ull : 0ull);
+    exhausted = false;
   }
   TOHC_DEV bool getedgedist(V3 fnrm, V3 a, V3 b, float &dist) {  // [epa:698-733]
     V3 ba = b - a;
@@ -1047,6 +1067,9 @@ struct Epa {
       if (freeLo) { face = (unsigned)__builtin_ctzll(freeLo); freeLo &= freeLo - 1; }
       else { face = 64u + (unsigned)__builtin_ctzll(freeHi); freeHi &= freeHi - 1; }
       hullAppend(face);
+#if defined(TOHC_EPA_PROF) && defined(__HIPCC__)
+      if (face > prof.maxface) prof.maxface = face;
+#endif
       m->fcp[face] = a | (b << 8) | (c << 16);   // pass = 0
       V3 aw = svW(a), bw = svW(b), cw = svW(c);
       V3 n = cross(bw - aw, cw - aw);
@@ -1067,6 +1090,7 @@ struct Epa {
       return TOHC_NIL;
     }
     status = E_OUTOFFACES;
+    if (limF < TOHC_EPA_MAX_FACES) exhausted = true;
     return TOHC_NIL;
   }
   // findbest [epa:779-793] walks the hull list from its root (newest face first) and keeps the first strict
@@ -1076,7 +1100,7 @@ struct Epa {
   TOHC_DEV unsigned findbest() {
     float best = INFINITY;
     int bkey = -1;   // (stamp << 8) | face; larger = earlier in the list
-    for (unsigned f = (unsigned)Grp<G>::lane(); f < TOHC_EPA_MAX_FACES; f += G) {
+    for (unsigned f = (unsigned)Grp<G>::lane(); f < (unsigned)MEM::kNF; f += G) {
       if (!onHull(f)) continue;
       const float d = m->fnd[f][3];
       const float sqd = d * d;
@@ -1119,7 +1143,7 @@ struct Epa {
           } else {
             ((uint8_t *)&m->fcp[f])[3] = (uint8_t)pass;
             m->stk[sp - 1] = (uint16_t)(f | (e << 8) | (1u << 10));
-            if (sp >= TOHC_EPA_MAX_FACES) { ret = false; --sp; continue; }  // cannot happen: depth <= hull faces
+            if (sp >= MEM::kNF) { ret = false; --sp; continue; }  // cannot happen: depth <= hull faces
             m->stk[sp] = (uint16_t)(byteOf(fw, e1) | (byteOf(ew, e1) << 8));
             ++sp;
           }
@@ -1149,7 +1173,7 @@ struct Epa {
     return ret;
   }
 
-  TOHC_DEV int evaluate(Gjk2<G, EpaMem> &g, V3 guess) {  // [epa:594-697]
+  TOHC_DEV int evaluate(Gjk2<G, MEM> &g, V3 guess) {  // [epa:594-697]
     const unsigned s = g.current;
     TOHC_PROF_T0(tenc);
     const bool enclosed = (g.rk(s) > 1) && g.encloseOrigin();
@@ -1184,7 +1208,7 @@ struct Epa {
         bind(t2, 2, t3, 1);
         status = E_VALID;
         for (; iterations < 255; ++iterations) {
-          if (nextsv < TOHC_EPA_MAX_VERTICES) {
+          if (nextsv < limV) {
             hcf = TOHC_NIL; hff = TOHC_NIL; hnf = 0;
             unsigned w = 4 + nextsv++;
             bool valid = true;
@@ -1213,10 +1237,13 @@ struct Epa {
                 ocp = m->fcp[best];
               } else { status = E_INVALIDHULL; break; }
             } else { status = E_ACCURACY; break; }
-          } else { status = E_OUTOFVERTICES; break; }
+          } else { status = E_OUTOFVERTICES; if (limV < TOHC_EPA_MAX_VERTICES) exhausted = true; break; }
         }
         TOHC_STAT(emuStats().epa_calls++; emuStats().epa_iters += iterations; emuStats().epa_faces += hullCount;
                   emuStats().hist_epa[iterations < 71 ? iterations : 71]++; emuStats().status[status]++;)
+#if defined(TOHC_EPA_PROF) && defined(__HIPCC__)
+        prof.nsv = nextsv;
+#endif
         const unsigned oc0 = byteOf(ocp, 0), oc1 = byteOf(ocp, 1), oc2 = byteOf(ocp, 2);
         V3 projection = outerN * outerD;
         normal = outerN;
@@ -1298,16 +1325,19 @@ TOHC_DEV bool penStage1(MEM *mem, const Cvx<G> &A, const Cvx<G> &B, const Xf &tA
   return false;
 }
 // g: the state penStage1 left (restored into an EpaMem when the stages run in different kernels)
-template <int G>
-TOHC_DEV void penStage2(EpaMem *mem, const Xf &tA, const Xf &tB, Gjk2<G, EpaMem> &g, bool &isValid2, V3 &v, V3 &wA, V3 &wB, EpaProf *prof = nullptr) {
+// returns false when MEM is smaller than the reference's pools and ran out (nothing is written then)
+template <int G, class MEM>
+TOHC_DEV bool penStage2(MEM *mem, const Xf &tA, const Xf &tB, Gjk2<G, MEM> &g, bool &isValid2, V3 &v, V3 &wA, V3 &wB, EpaProf *prof = nullptr,
+                        unsigned limV = MEM::kNV, unsigned limF = MEM::kNF) {
   V3 guess = tA.o - tB.o;
-  Epa<G> e;
+  Epa<G, MEM> e;
   e.m = mem;
 #if defined(TOHC_EPA_PROF) && defined(__HIPCC__)
   for (int k = 0; k < 8; ++k) { e.prof.t[k] = 0; e.prof.n[k] = 0; }
+  e.prof.maxface = 0; e.prof.nsv = 0;
 #endif
   TOHC_PROF_T0(ti);
-  e.init();
+  e.init(limV, limF);
   TOHC_PROF_ACC(e.prof, 0, ti);
   TOHC_PROF_T0(tev);
   e.evaluate(g, -guess);  // never leaves E_FAILED: every path sets a status, so the reference's Distance fall-back is dead here
@@ -1315,6 +1345,7 @@ TOHC_DEV void penStage2(EpaMem *mem, const Xf &tA, const Xf &tB, Gjk2<G, EpaMem>
 #if defined(TOHC_EPA_PROF) && defined(__HIPCC__)
   if (prof) *prof = e.prof;
 #endif
+  if (e.exhausted) return false;
   V3 w0 = mk(0, 0, 0);
   for (unsigned i = 0; i < e.rrank; ++i) {
     unsigned ci = e.rc[0];
@@ -1327,6 +1358,7 @@ TOHC_DEV void penStage2(EpaMem *mem, const Xf &tA, const Xf &tB, Gjk2<G, EpaMem>
   wB = xfApply(tA, w0 - e.normal * e.depth);
   v = -e.normal;
   isValid2 = true;
+  return true;
 }
 
 // second half of getClosestPointsNonVirtual [gjk:334-449]: penetration / degenerate handling and the output filter
@@ -1411,8 +1443,8 @@ TOHC_DEV void penSave(PenHand &h, const Gjk2<G, MEM> &g) {
   g2Copy(&h.mem, g.m);
   h.rank0 = g.rank0; h.rank1 = g.rank1; h.nfree = g.nfree; h.current = g.current;
 }
-template <int G>
-TOHC_DEV void penRestore(EpaMem *mem, const PenHand &h, const Cvx<G> &A, const Cvx<G> &B, const Xf &lA, const Xf &lB, Gjk2<G, EpaMem> &g) {
+template <int G, class MEM>
+TOHC_DEV void penRestore(MEM *mem, const PenHand &h, const Cvx<G> &A, const Cvx<G> &B, const Xf &lA, const Xf &lB, Gjk2<G, MEM> &g) {
   g2Copy(mem, &h.mem);
   g.m = mem;
   g.rank0 = h.rank0; g.rank1 = h.rank1; g.nfree = h.nfree; g.current = h.current;
