@@ -250,6 +250,17 @@ int tohc_get_counters(const tohc_engine *e, tohc_counters *out);
 /* capacity knobs (defaults sized for SURVEY config 4 on one MI355X) */
 int tohc_set_capacity(tohc_engine *e, int64_t max_pairs, int64_t max_records);
 
+/* replaces btShapeHull(&btConvexTriangleMeshShape).buildHull() as createShapePrimitive calls it for a triangle mesh
+ *                                                            src/trajopt/bullet_collision_checker.cpp:174-203
+ *          ext/bullet/src/BulletCollision/CollisionShapes/btShapeHull.cpp:38-100, LinearMath/btConvexHull.cpp:691-812
+ * The engine takes the FINAL points of a TOHC_HULL shape; for a mesh this is how to get them.  verts: n_verts x 3,
+ * tri: n_tri x 3 vertex numbers (the mesh's index list, in its order: ties between support vertices go to the corner
+ * named first).  Meshes of fewer than 50 vertices are used as they are, larger ones are reduced to the hull of their 42
+ * support points (<= 42 points, values and order as the reference's btConvexHullShape holds them; fp32 host code, no
+ * GPU, no engine).  Writes min(result, cap) points to out and returns the result's point count (call with cap = 0 to
+ * ask), or TOHC_E_INVALID. */
+int tohc_shape_hull(const float *verts, int n_verts, const int32_t *tri, int n_tri, float *out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

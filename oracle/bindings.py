@@ -276,6 +276,20 @@ def load_oracle():
     return C.CDLL(os.path.join(HERE, "liboracle.so"))
 
 
+def ref_shape_hull(vertices, triangles):
+    """The reference's own btShapeHull over a btConvexTriangleMeshShape (ref_driver.cpp: ref_shape_hull), as
+    createShapePrimitive calls it (bullet_collision_checker.cpp:174-203)."""
+    lib = load_ref()
+    v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
+    t = np.ascontiguousarray(triangles, np.int32).reshape(-1, 3)
+    cap = max(len(v), 64)
+    out = np.zeros((cap, 3), np.float32)
+    lib.ref_shape_hull.restype = C.c_int
+    n = lib.ref_shape_hull(v.ctypes.data_as(C.POINTER(C.c_float)), len(v), t.ctypes.data_as(C.POINTER(C.c_int)), len(t),
+                           out.ctypes.data_as(C.POINTER(C.c_float)), cap)
+    return out[:n].copy()
+
+
 def ref_world(scene, **kw):
     return World(load_ref(), "ref_", scene, **kw)
 

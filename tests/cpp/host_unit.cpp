@@ -209,10 +209,21 @@ static void addGeoms(KinBody::Link& link, const Flat& F, int obj) {
       case TOHC_BOX: g.type = GT_Box, g.boxExtents = Vector(param[4 * s], param[4 * s + 1], param[4 * s + 2]); break;
       case TOHC_CYLZ: g.type = GT_Cylinder, g.radius = param[4 * s], g.height = 2 * param[4 * s + 1]; break;
       case TOHC_SPHERE: g.type = GT_Sphere, g.radius = param[4 * s]; break;
-      case TOHC_HULL:
+      case TOHC_HULL: {
         g.type = GT_TriMesh;
-        for (int v = (int)voff[s]; v < (int)(voff[s] + vcnt[s]); ++v) g.meshVertices.push_back(Vector(verts[3 * v], verts[3 * v + 1], verts[3 * v + 2]));
+        const vector<double>&mvoff = F.at("mesh_voff"), &mvcnt = F.at("mesh_vcnt"), &mtoff = F.at("mesh_toff"), &mtcnt = F.at("mesh_tcnt"),
+                            &mverts = F.at("mesh_verts"), &mtris = F.at("mesh_tris");
+        if (mvcnt[s] > 0) {   // the geometry's own mesh (Scene.add_trimesh): the checker reduces it
+          for (int v = (int)mvoff[s]; v < (int)(mvoff[s] + mvcnt[s]); ++v) g.mesh.vertices.push_back(Vector(mverts[3 * v], mverts[3 * v + 1], mverts[3 * v + 2]));
+          for (int t = 3 * (int)mtoff[s]; t < 3 * (int)(mtoff[s] + mtcnt[s]); ++t) g.mesh.indices.push_back((int)mtris[t]);
+        } else {              // hull points given directly: a strip of triangles over them (fewer than 50: used as they are)
+          for (int v = (int)voff[s]; v < (int)(voff[s] + vcnt[s]); ++v) g.mesh.vertices.push_back(Vector(verts[3 * v], verts[3 * v + 1], verts[3 * v + 2]));
+          if ((int)vcnt[s] >= 50) throw std::runtime_error("flat world: hulls of 50 points or more need their mesh");
+          for (int v = 0; v + 2 < std::max((int)vcnt[s], 3); ++v)
+            for (int k = 0; k < 3; ++k) g.mesh.indices.push_back(std::min(v + k, (int)vcnt[s] - 1));
+        }
         break;
+      }
       default: throw std::runtime_error("flat world: unsupported shape kind");
     }
     link.m_geoms.push_back(g);

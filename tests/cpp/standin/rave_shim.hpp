@@ -65,6 +65,11 @@ enum JointType { JointFixed = 0, JointRevolute = 1, JointPrismatic = 2 };
 class KinBody;
 class EnvironmentBase;
 
+struct TriMesh {   // OpenRAVE::TriMesh: GetCollisionMesh() of a GT_TriMesh geometry
+  std::vector<Vector> vertices;
+  std::vector<int> indices;   // three per triangle
+};
+
 class KinBody {
  public:
   class Link {
@@ -73,7 +78,8 @@ class KinBody {
       GeometryType type = GT_None;
       Vector boxExtents;               // GT_Box: half extents (GetBoxExtents)
       double radius = 0, height = 0;   // GT_Sphere / GT_Cylinder (full height, GetCylinderHeight)
-      std::vector<Vector> meshVertices;  // GT_TriMesh: the points of the convex geometry
+      TriMesh mesh;                    // GT_TriMesh
+      const TriMesh& GetCollisionMesh() const { return mesh; }
       Transform t;                     // GetTransform(): geometry frame in the link frame
       GeometryType GetType() const { return type; }
       const Transform& GetTransform() const { return t; }

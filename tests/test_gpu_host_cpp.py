@@ -61,6 +61,21 @@ def _world(cfg):
         q0 = rb.q_robot[1:8] + rng.uniform(-0.5, 0.5, size=7)
         traj = synth.straight_line(q0, q0 + rng.uniform(-0.9, 0.9, size=7), 8)
         return s, rb, static_T, 0.09, traj, 0.05
+    if cfg == "arm_meshes":     # GT_TriMesh obstacles of 60..800 vertices: the checker's btShapeHull reduction (tohc_shape_hull, :174-203)
+        s = M.Scene()
+        rb = synth.pr2_like(s, seed=0, active="rightarm")
+        rng = np.random.default_rng(13)
+        ids, Ts = [], []
+        for i in range(8):
+            v, t = synth.random_trimesh(rng, int(rng.choice([40, 60, 200, 800])), int(rng.choice([0, 1, 3])))
+            v = ((v - v.mean(0)) * 0.4).astype(np.float32)
+            ids.append(s.add_object([(s.add_trimesh(v, t), M.IDENT7)], M.GROUP_KINBODY))
+            Ts.append(synth.T7(rng.uniform([0.3, -0.8, 0.4], [0.9, 0.2, 1.2]), rng.normal(size=3), rng.uniform(0, 3)))
+        s.finalize(); rb.finalize()
+        static_T = synth.static_poses(s, ids, np.array(Ts))
+        q0 = rb.q_robot[1:8] + rng.uniform(-0.5, 0.5, size=7)
+        traj = synth.straight_line(q0, q0 + rng.uniform(-0.9, 0.9, size=7), 8)
+        return s, rb, static_T, 0.09, traj, 0.05
     s, rb, static_T, d = synth.config_fullbody_soup(n_hulls=256)    # configs[3] with a smaller soup, 12 timesteps
     traj = synth.fullbody_trajectory(rb, np.random.default_rng(1000), 12)
     return s, rb, static_T, d, traj, 0.05
@@ -69,7 +84,7 @@ def _world(cfg):
 KEY = ("t", "idA", "childA", "idB", "childB")
 
 
-@pytest.mark.parametrize("cfg", ["arm_table", "fullbody_soup256", "arm_grab_spheres"])
+@pytest.mark.parametrize("cfg", ["arm_table", "fullbody_soup256", "arm_grab_spheres", "arm_meshes"])
 def test_cpp_collision_terms_vs_python_host_and_oracle(built, tmp_path, cfg):
     s, rb, static_T, d, traj, dist_pen = _world(cfg)
     coeff = 20.0

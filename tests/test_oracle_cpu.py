@@ -220,6 +220,74 @@ def test_oracle_vs_reference_bullet_random(built, seed):
         w.close()
 
 
+def test_shape_hull_golden_fixture_bit_exact(built):
+    """tohc_shape_hull (the btShapeHull reduction of a GT_TriMesh, bullet_collision_checker.cpp:174-203) against points
+    recorded from the reference's own Bullet (tests/golden/make_shape_hull.py): values and order."""
+    from trajopt_amd import engine
+    z = np.load(os.path.join(ROOT, "tests", "golden", "shape_hull.npz"), allow_pickle=False)
+    sizes = set()
+    for k in range(int(z["n"])):
+        v, t, h = z["v%d" % k], z["t%d" % k], z["h%d" % k]
+        mine = engine.shape_hull(v, t)
+        assert mine.shape == h.shape and np.array_equal(mine.view(np.uint32), h.view(np.uint32)), k
+        if len(v) < 50:
+            assert np.array_equal(mine, v)          # used verbatim (:189-201)
+        else:
+            assert len(mine) <= 42
+        sizes.add(len(mine))
+    assert 4 in sizes and max(sizes) >= 40           # flat meshes collapse to a quad, blobs keep ~42 points
+    # bad index list
+    lib = engine.load_library()
+    v = np.zeros((3, 3), np.float32); t = np.array([[0, 1, 3]], np.int32)
+    assert lib.tohc_shape_hull(v.ctypes.data_as(C.POINTER(C.c_float)), 3, t.ctypes.data_as(C.POINTER(C.c_int32)), 1, None, 0) == -1
+
+
+@pytest.mark.skipif(not B.ref_available(), reason="oracle/_ref/libref.so is only built where /root/reference exists")
+def test_shape_hull_vs_reference_bullet_random(built):
+    from trajopt_amd import engine
+    for seed in range(200):
+        rng = np.random.default_rng(7100 + seed)
+        v, t = synth.random_trimesh(rng, int(rng.choice([30, 50, 60, 200, 1000])), seed % 4)
+        a, b = B.ref_shape_hull(v, t), engine.shape_hull(v, t)
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), seed
+
+
+@pytest.mark.skipif(not B.ref_available(), reason="oracle/_ref/libref.so is only built where /root/reference exists")
+def test_trimesh_objects_through_shape_hull_vs_reference_bullet(built):
+    """A world whose objects are GT_TriMesh geometries of 60..800 vertices, reduced by tohc_shape_hull (Scene.add_trimesh):
+    discrete and cast contacts of the oracle and of the host build of the device code equal those of the reference's
+    Bullet on ITS btShapeHull points, bit for bit."""
+    rng = np.random.default_rng(7300)
+    s, sr = M.Scene(), M.Scene()
+    objT, robot = [], []
+    for i in range(10):
+        v, t = synth.random_trimesh(rng, int(rng.choice([60, 200, 800])), int(rng.choice([0, 0, 1, 3])))
+        v = ((v - v.mean(0)) * 0.5).astype(np.float32)
+        grp = M.GROUP_ROBOT if i < 4 else M.GROUP_KINBODY
+        s.add_object([(s.add_trimesh(v, t), M.IDENT7)], grp, name="mesh%d" % i)
+        sr.add_object([(sr.add_hull(B.ref_shape_hull(v, t)), M.IDENT7)], grp, name="mesh%d" % i)
+        if i < 4:
+            robot.append(i)
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        objT.append(np.concatenate([q, rng.uniform(-0.25, 0.25, 3)]))
+    s.finalize(); sr.finalize()
+    objT = np.array(objT)
+    T1 = objT[robot].copy()
+    T1[:, 4:] += rng.normal(size=(len(robot), 3)) * 0.1
+    wr, wo, we = B.ref_world(sr), B.oracle_world(s), util.emu_world(s)
+    for w in (wr, wo, we):
+        w.set_contact_distance(0.09)
+    ref = wr.links_vs_all(objT, robot)
+    assert len(ref) > 5
+    util.assert_same_contacts(wo.links_vs_all(objT, robot), ref, "oracle disc")
+    util.assert_same_contacts(we.links_vs_all(objT, robot), ref, "emu disc")
+    refc = wr.cast_vs_all(objT, robot, objT[robot], T1)
+    util.assert_same_contacts(wo.cast_vs_all(objT, robot, objT[robot], T1), refc, "oracle cast")
+    util.assert_same_contacts(we.cast_vs_all(objT, robot, objT[robot], T1), refc, "emu cast")
+    for w in (wr, wo, we):
+        w.close()
+
+
 def test_epa_small_pools_then_full_pools_same_results(built, tmp_path):
     """k_tail_epa runs EPA on small pools first and repeats a run that leaves them on the reference's pools.  Here the
     host build of the device source is compiled with pools so small (6 support vertices, 10 faces) that most runs are

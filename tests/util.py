@@ -76,6 +76,14 @@ def write_flat_world(path, scene, rb, static_T, traj, d, dist_pen, coeff):
     items.update({k: r[k] for k in ("parent", "jtype", "T_origin", "axis", "dof", "mult", "offs", "link_obj", "q_robot", "base_T", "joint_inds", "rot_axis")})
     items.update(static_T=static_T, traj=traj, d=[d], dist_pen=[dist_pen], coeff=[coeff], n_dof=[rb.n_dof], affine=[rb.affine],
                  n_joint_inds=[len(rb.joint_inds)])
+    # GT_TriMesh geometries (Scene.add_trimesh): the mesh itself, so that the C++ checker does the btShapeHull reduction
+    ns = len(a["kind"])
+    mvoff, mvcnt, mtoff, mtcnt, mv, mt = np.zeros(ns), np.zeros(ns), np.zeros(ns), np.zeros(ns), [], []
+    for sid, (v, t) in sorted(scene.mesh_src.items()):
+        mvoff[sid], mvcnt[sid], mtoff[sid], mtcnt[sid] = sum(len(x) for x in mv), len(v), sum(len(x) for x in mt), len(t)
+        mv.append(v); mt.append(t)
+    items.update(mesh_voff=mvoff, mesh_vcnt=mvcnt, mesh_toff=mtoff, mesh_tcnt=mtcnt,
+                 mesh_verts=np.concatenate(mv) if mv else np.zeros(0), mesh_tris=np.concatenate(mt) if mt else np.zeros(0))
     with open(path, "w") as f:
         for k, v in items.items():
             v = np.asarray(v).ravel()

@@ -87,6 +87,7 @@ SYMBOLS = {
     "tohc_ray_cast_poses_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),   # device pointers
     "tohc_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "tohc_set_capacity": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64]),
+    "tohc_shape_hull": (C.c_int, [_f32p, C.c_int, _i32p, C.c_int, _f32p, C.c_int]),
 }
 
 
@@ -106,6 +107,21 @@ def load_library():
 
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
+
+
+def shape_hull(vertices, triangles):
+    """The points createShapePrimitive gives a GT_TriMesh geometry's btConvexHullShape (bullet_collision_checker.cpp:
+    174-203): the mesh's own vertices below 50 of them, else btShapeHull's <= 42 points (tohc_shape_hull; host code, no
+    GPU needed)."""
+    lib = load_library()
+    v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
+    t = np.ascontiguousarray(triangles, np.int32).reshape(-1, 3)
+    n = lib.tohc_shape_hull(_p(v, C.c_float), len(v), _p(t, C.c_int32), len(t), None, 0)
+    if n < 0:
+        raise EngineError(n, "tohc_shape_hull: bad mesh (an index outside the vertex table?)")
+    out = np.zeros((n, 3), np.float32)
+    lib.tohc_shape_hull(_p(v, C.c_float), len(v), _p(t, C.c_int32), len(t), _p(out, C.c_float), n)
+    return out
 
 
 class Engine:

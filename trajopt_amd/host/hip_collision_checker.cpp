@@ -88,13 +88,22 @@ void HIPCollisionChecker::Rebuild(const vector<OR::KinBodyPtr>& bodies) {
           case OR::GT_Box: kind.push_back(TOHC_BOX), p[0] = (float)g.boxExtents.x, p[1] = (float)g.boxExtents.y, p[2] = (float)g.boxExtents.z; break;
           case OR::GT_Sphere: kind.push_back(TOHC_SPHERE), p[0] = (float)g.radius; break;
           case OR::GT_Cylinder: kind.push_back(TOHC_CYLZ), p[0] = (float)g.radius, p[1] = (float)(g.height / 2.); break;   // :153-158
-          case OR::GT_TriMesh:
-            // the engine takes the FINAL hull points: meshes of >= 50 vertices are reduced by btShapeHull in the
-            // reference (:174-203); that reduction is host-side set-up the caller runs once
-            if (g.meshVertices.empty() || g.meshVertices.size() > 64) throw std::runtime_error("HIPCollisionChecker: convex geometry needs 1..64 points");
+          case OR::GT_TriMesh: {
+            // :160-203: below 50 vertices the mesh's vertices are the hull's points, from 50 on btShapeHull's <= 42
+            // support points (tohc_shape_hull restates btShapeHull::buildHull + HullLibrary)
+            const OR::TriMesh& mesh = g.GetCollisionMesh();
+            if (mesh.indices.size() < 3) throw std::runtime_error("HIPCollisionChecker: triangle mesh without triangles");   // assert, :162
+            vector<float> mv;
+            for (const Vector& v : mesh.vertices) mv.push_back((float)v.x), mv.push_back((float)v.y), mv.push_back((float)v.z);   // toBt, :166
+            vector<int32_t> mi(mesh.indices.begin(), mesh.indices.begin() + mesh.indices.size() / 3 * 3);
+            int n = tohc_shape_hull(mv.data(), (int)mesh.vertices.size(), mi.data(), (int)mi.size() / 3, NULL, 0);
+            if (n < 1 || n > 64) throw std::runtime_error("HIPCollisionChecker: convex geometry needs 1..64 points (meshes of 50..64 vertices that btShapeHull cannot reduce excepted, the engine's hulls hold at most 64)");
+            vector<float> hull((size_t)3 * n);
+            tohc_shape_hull(mv.data(), (int)mesh.vertices.size(), mi.data(), (int)mi.size() / 3, hull.data(), n);
             kind.push_back(TOHC_HULL);
-            for (const Vector& v : g.meshVertices) vx.push_back((float)v.x), vy.push_back((float)v.y), vz.push_back((float)v.z);
+            for (int i = 0; i < n; ++i) vx.push_back(hull[3 * i]), vy.push_back(hull[3 * i + 1]), vz.push_back(hull[3 * i + 2]);
             break;
+          }
           default: throw std::runtime_error("unrecognized collision shape type");   // :208
         }
         vcnt.push_back((int32_t)vx.size() - voff.back());

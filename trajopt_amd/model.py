@@ -32,6 +32,7 @@ class Scene:
         self.child_shape, self.child_T = [], []
         self.obj_off, self.obj_cnt, self.obj_compound, self.obj_group = [], [], [], []
         self.obj_name = []
+        self.mesh_src = {}   # shape id -> (vertices, triangles) of a GT_TriMesh geometry (add_trimesh)
         self.arrays = None
 
     # -- shapes ----------------------------------------------------------------------------------------
@@ -53,6 +54,14 @@ class Scene:
         if not 1 <= len(pts) <= 64:
             raise ValueError("hull shapes hold 1..64 vertices (the reference reduces meshes to <= 42)")
         return self._shape(HULL, (0, 0, 0, 0), pts)
+
+    def add_trimesh(self, vertices, triangles):
+        """GT_TriMesh (bullet_collision_checker.cpp:160-203): below 50 vertices the mesh's vertices are the hull's points,
+        from 50 on btShapeHull's reduction to <= 42 points (engine.shape_hull = tohc_shape_hull)."""
+        from . import engine
+        sid = self.add_hull(engine.shape_hull(vertices, triangles))
+        self.mesh_src[sid] = (np.ascontiguousarray(vertices, np.float32).reshape(-1, 3), np.ascontiguousarray(triangles, np.int32).reshape(-1, 3))
+        return sid
 
     def _shape(self, kind, param, pts):
         self.kind.append(kind)

@@ -68,6 +68,30 @@ def blob_hull(rng, scale=(0.05, 0.05, 0.15), npts=200, nverts=42, center=(0, 0, 
     return pts[idx].astype(np.float32)
 
 
+def random_trimesh(rng, n, kind):
+    """A triangle mesh (fp32 vertices [n][3], int32 triangles [m][3]) as a GT_TriMesh geometry would hold it: kind 0 an
+    anisotropic blob's surface, 1 a cloud with interior points, 2 a nearly flat slab, 3 a 24-gon prism with repeated
+    points.  Triangles: the cloud's hull facets (scipy's Qhull, joggled), so interior points are named by no triangle."""
+    from scipy.spatial import ConvexHull
+    if kind == 0:
+        p = rng.normal(size=(n, 3))
+        p /= np.linalg.norm(p, axis=1)[:, None]
+        p *= rng.uniform(0.05, 0.5, 3) * rng.uniform(0.8, 1.2, (n, 1))
+    elif kind == 1:
+        p = rng.uniform(-1, 1, (n, 3)) * rng.uniform(0.05, 0.6, 3)
+    elif kind == 2:
+        p = rng.uniform(-1, 1, (n, 3)) * np.array([0.5, 0.3, 1e-4])
+    else:
+        a = rng.integers(0, 24, n) * (2 * np.pi / 24)
+        p = np.stack([0.2 * np.cos(a), 0.2 * np.sin(a), rng.choice([-0.3, 0.3], n)], 1)
+    p = (p + rng.uniform(-1, 1, 3)).astype(np.float32)
+    try:
+        tri = ConvexHull(p.astype(np.float64), qhull_options="QJ").simplices.astype(np.int32)
+    except Exception:   # degenerate for Qhull: a strip over consecutive vertices
+        tri = np.stack([np.arange(n - 2), np.arange(1, n - 1), np.arange(2, n)], 1).astype(np.int32)
+    return p, tri
+
+
 def random_scene(rng, n_static=6, n_robot=4, compound_prob=0.5, box_prob=0.4, spread=0.6, round_prob=0.0, spheres=False):
     """A small world with mixed boxes / hulls (and, with round_prob > 0, z-cylinders; spheres only on request -- the
     engine rejects them), bare shapes and compounds.  Returns (scene, objT, robot_ids).  round_prob = 0 draws exactly the scenes of the golden fixtures."""
