@@ -250,6 +250,19 @@ int tohc_get_counters(const tohc_engine *e, tohc_counters *out);
 /* capacity knobs (defaults sized for SURVEY config 4 on one MI355X) */
 int tohc_set_capacity(tohc_engine *e, int64_t max_pairs, int64_t max_records);
 
+/* replaces BulletCollisionChecker::AllVsAll                   src/trajopt/bullet_collision_checker.cpp:463-498, 415-422
+ * (performDiscreteCollisionDetection + a walk over the dispatcher's persistent manifolds) at the given object poses
+ * [n_objects][7].  Every unordered pair of objects once -- the allowed matrix is read at (lower, higher) object number,
+ * as the near callback's CanCollide(proxy0, proxy1), and again at (A, B) as the manifold walk does (:484) -- with
+ * Bullet's roles for A and B; contacts are kept up to the
+ * manifolds' breaking threshold 2.001 d (there is no CollisionCollector on this path), and dist / ptA / ptB have been
+ * through the manifold's local-frame round trip (btManifoldResult::addContactPoint, refreshContactPoints), as the
+ * reference reads them.  Every convex pair owns a manifold with one point, so the reference's weight 1 / numContacts is
+ * 1 for every record.  (The reference's manifolds also remember the contact distance they were created under; this is
+ * the result of a checker whose distance was set before the first call.)  Records as tohc_links_vs_all_poses, no
+ * gradient rows. */
+int tohc_all_vs_all_poses(tohc_engine *e, const double *obj_T, const tohc_record **records, int *n_records);
+
 /* replaces btShapeHull(&btConvexTriangleMeshShape).buildHull() as createShapePrimitive calls it for a triangle mesh
  *                                                            src/trajopt/bullet_collision_checker.cpp:174-203
  *          ext/bullet/src/BulletCollision/CollisionShapes/btShapeHull.cpp:38-100, LinearMath/btConvexHull.cpp:691-812

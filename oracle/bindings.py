@@ -163,6 +163,25 @@ class World:
         assert n <= self.cap
         return self.buf[:n].copy()
 
+    def all_vs_all(self, objT):
+        """AllVsAll (bullet_collision_checker.cpp:463-498); the reference driver also returns 1 / numContacts per point, which
+        this asserts to be 1.  The reference's manifolds keep the breaking threshold they were created under: set the
+        contact distance before the first call."""
+        objT = np.ascontiguousarray(objT, np.float64)
+        out = np.zeros(self.cap, CONTACT_DTYPE)
+        f = self.f("all_vs_all")
+        f.restype = C.c_int
+        if self.px == "ref_":
+            wt = np.zeros(self.cap)
+            f.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_double), C.c_int]
+            n = f(self.h, objT.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.c_void_p), wt.ctypes.data_as(C.POINTER(C.c_double)), self.cap)
+            assert n <= self.cap and (wt[:n] == 1.0).all()
+        else:
+            f.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_int]
+            n = f(self.h, objT.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.c_void_p), self.cap)
+            assert n <= self.cap
+        return out[:n].copy()
+
     def cast_vs_all(self, objT, query, T0, T1):
         objT = np.ascontiguousarray(objT, np.float64).reshape(-1, 7)
         q = np.ascontiguousarray(query, np.int32)

@@ -433,6 +433,46 @@ int ref_ray_cast(void* h, const double* objT, const double* from3, const double*
   return hits;
 }
 
+/* AllVsAll (bullet_collision_checker.cpp:463-498) with its near callback (:415-422): performDiscreteCollisionDetection,
+ * then every point of every persistent manifold with weight 1 / numContacts; manifolds cleared afterwards.  childA / childB
+ * = the manifold point's m_index0 / m_index1 (the compound algorithm's shape identifiers; -1 for a bare shape). */
+static void refNearCallback(btBroadphasePair& pair, btCollisionDispatcher& dispatcher, const btDispatcherInfo& info) {
+  World* w = static_cast<World*>(dispatcher.m_userData);
+  if (w->canCollide(static_cast<Obj*>(pair.m_pProxy0->m_clientObject)->id, static_cast<Obj*>(pair.m_pProxy1->m_clientObject)->id))
+    dispatcher.defaultNearCallback(pair, dispatcher, info);
+}
+int ref_all_vs_all(void* h, const double* objT, ora_contact* out, double* weight, int cap) {
+  World* w = (World*)h;
+  syncWorld(w, objT);
+  w->disp->setNearCallback(&refNearCallback);
+  w->disp->m_userData = w;
+  w->world->performDiscreteCollisionDetection();
+  int n = 0;
+  for (int i = 0; i < w->disp->getNumManifolds(); ++i) {
+    btPersistentManifold* m = w->disp->getManifoldByIndexInternal(i);
+    const int nc = m->getNumContacts();
+    const Obj* A = static_cast<const Obj*>(m->getBody0());
+    const Obj* B = static_cast<const Obj*>(m->getBody1());
+    for (int j = 0; j < nc; ++j) {
+      btManifoldPoint& pt = m->getContactPoint(j);
+      if (w->canCollide(A->id, B->id)) {
+        if (n < cap) {
+          ora_contact c;
+          memset(&c, 0, sizeof c);
+          c.objA = A->id, c.objB = B->id, c.childA = pt.m_index0, c.childB = pt.m_index1;
+          for (int k = 0; k < 3; ++k) c.ptA[k] = pt.getPositionWorldOnA()[k], c.ptB[k] = pt.getPositionWorldOnB()[k], c.n[k] = pt.m_normalWorldOnB[k];
+          c.dist = pt.m_distance1;
+          out[n] = c;
+          weight[n] = 1. / nc;
+        }
+        ++n;
+      }
+    }
+    m->clearManifold();
+  }
+  return n;
+}
+
 /* Post-construction vertex data of a shape, for hull shapes built elsewhere (diagnostics). */
 int ref_gjk_checks(void) { return gNumGjkChecks; }
 int ref_epa_checks(void) { return gNumDeepPenetrationChecks; }

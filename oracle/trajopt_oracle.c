@@ -1131,6 +1131,7 @@ typedef struct {
   float *verts;     /* owned copy of the hull vertices */
   float d;          /* contact distance as float (SetContactDistance takes float) */
   float breaking;   /* gContactBreakingThreshold = 2.001*d (double product rounded to float) */
+  int all_pairs;    /* inside ora_all_vs_all: contacts are kept up to the breaking threshold */
   long pair_evals, aabb_tests;
 } world_t;
 
@@ -1307,7 +1308,7 @@ static int pairEval(world_t *w, const cvx_t *A, const xf *tA, const cvx_t *B, co
     gjkPair(A, B, tA, tB, md, &o);
   if (!o.valid) return 0;
   /* btBridgedManifoldResult::addContactPoint [cw:1068-1086]; CollisionCollector [bcc:398-408] */
-  if ((double)o.distance > (double)w->d) return 0;
+  if ((double)o.distance > (double)(w->all_pairs ? w->breaking : w->d)) return 0; /* AllVsAll: btManifoldResult::addContactPoint [mr:93-96] */
   v3 pA = vadd(o.pointOnB, vscale(o.normalOnB, o.distance));
   c->dist = o.distance;
   c->n[0] = o.normalOnB.x; c->n[1] = o.normalOnB.y; c->n[2] = o.normalOnB.z;
@@ -1360,6 +1361,85 @@ int ora_links_vs_all(void *h, const double *objT7, const int *q, int nq, int fil
       }
     }
   }
+  free(T);
+  return n;
+}
+
+/* AllVsAll [bcc:463-498]: performDiscreteCollisionDetection with the near callback of [bcc:415-422], then every point of
+ * every persistent manifold, weight 1 / numContacts.  What that amounts to with this configuration:
+ *   - every unordered object pair once, (obj0, obj1) = (lower, higher) id = order of addCollisionObject
+ *     (btBroadphasePair sorts its proxies by unique id); all proxy masks are AllFilter, so only CanCollide(obj0, obj1)
+ *     filters [bcc:418];
+ *   - the algorithms, and with them the GJK roles, are those contactTest(obj0) finds against obj1 (a compound's
+ *     child is A, the compound of obj1 winning; else obj0 is A);
+ *   - every convex pair owns a manifold [cca:300-306] that GJK feeds ONE point (no perturbation iterations in
+ *     btDefaultCollisionConfiguration), so numContacts = 1 and weight = 1;
+ *   - btManifoldResult::addContactPoint keeps the point up to the manifold's breaking threshold = 2.001 d
+ *     (NOT d: there is no CollisionCollector here), stores it in the two OBJECTS' frames and, own manifold,
+ *     refreshContactPoints [pm:199-259] then re-derives the world points from those and the distance as
+ *     (posA - posB) . normal -- the values AllVsAll reads;
+ *   - nothing in the cull loses a pair within 2 d (every box is grown by d, object boxes by another 2.001 d);
+ *     a compound child pair whose distance lies in (2 d, 2.001 d] may fail Bullet's child box test [cpa:128-132]; this
+ *     restatement keeps such a pair.
+ * Writes contacts with A / B in manifold order; returns the count. */
+int ora_all_vs_all(void *h, const double *objT7, ora_contact *out, int cap) {
+  world_t *w = (world_t *)h;
+  int n = 0;
+  xf *T = (xf *)malloc(sizeof(xf) * (w->n_objects + 1));
+  for (int i = 0; i < w->n_objects; ++i) T[i] = xfFrom7(objT7 + 7 * i);
+  w->all_pairs = 1;
+  for (int Q = 0; Q < w->n_objects; ++Q) {
+    for (int X = Q + 1; X < w->n_objects; ++X) {
+      if (!w->allowed[(size_t)Q * w->n_objects + X]) continue;
+      for (int qc = 0; qc < w->obj_cnt[Q]; ++qc) {
+        xf tq = childWorld(w, Q, qc, &T[Q]);
+        cvx_t cq = plainCvx(&w->shapes[w->child_shape[w->obj_off[Q] + qc]]);
+        aabb_t bq = shapeAabb(cq.s, &tq, w->breaking);
+        for (int xc = 0; xc < w->obj_cnt[X]; ++xc) {
+          xf tx = childWorld(w, X, xc, &T[X]);
+          cvx_t cx = plainCvx(&w->shapes[w->child_shape[w->obj_off[X] + xc]]);
+          aabb_t bx = shapeAabb(cx.s, &tx, w->breaking);
+          w->aabb_tests++;
+          if (!aabbOverlap(bq, bx)) continue;
+          ora_contact c;
+          memset(&c, 0, sizeof c);
+          int kept;
+          const xf *oA, *oB;
+          if (w->obj_compound[X]) {
+            kept = pairEval(w, &cx, &tx, &cq, &tq, &c);
+            c.objA = X; c.childA = xc; c.objB = Q; c.childB = qc;
+            oA = &T[X]; oB = &T[Q];
+          } else {
+            kept = pairEval(w, &cq, &tq, &cx, &tx, &c);
+            c.objA = Q; c.childA = qc; c.objB = X; c.childB = xc;
+            oA = &T[Q]; oB = &T[X];
+          }
+          if (!kept) continue;
+          /* the manifold walk asks CanCollide again, in the manifold's order of the two objects [bcc:484]; with a
+           * one-directional exclusion (ExcludeCollisionPair, bcc:342-346) that is a second condition */
+          if (!w->allowed[(size_t)c.objA * w->n_objects + c.objB]) continue;
+          /* btManifoldResult::addContactPoint [mr:85-126] -> refreshContactPoints [pm:199-259] */
+          v3 nW = V((float)c.n[0], (float)c.n[1], (float)c.n[2]);
+          v3 pointA = V((float)c.ptA[0], (float)c.ptA[1], (float)c.ptA[2]);
+          v3 pointB = V((float)c.ptB[0], (float)c.ptB[1], (float)c.ptB[2]);
+          v3 localA = mulVM(vsub(pointA, oA->o), &oA->b); /* invXform, btTransform.h:218-222 */
+          v3 localB = mulVM(vsub(pointB, oB->o), &oB->b);
+          v3 posA = xfApply(oA, localA), posB = xfApply(oB, localB);
+          float dist = vdot(vsub(posA, posB), nW);
+          if (!(dist <= w->breaking)) continue; /* validContactDistance */
+          v3 projected = vsub(posA, vscale(nW, dist));
+          v3 diff = vsub(posB, projected);
+          if (vdot(diff, diff) > w->breaking * w->breaking) continue;
+          c.dist = dist;
+          c.ptA[0] = posA.x; c.ptA[1] = posA.y; c.ptA[2] = posA.z;
+          c.ptB[0] = posB.x; c.ptB[1] = posB.y; c.ptB[2] = posB.z;
+          if (n < cap) out[n] = c;
+          ++n;
+        }
+      }
+    }
+  }
+  w->all_pairs = 0;
   free(T);
   return n;
 }

@@ -62,7 +62,10 @@ static void test_box_distance() {
     checker->BodyVsAll(*box0, bodyvsall_collisions);         \
     EXPECT_EQ((size_t)(n), bodyvsall_collisions.size());     \
   }
-  // (the reference comments the AllVsAll count out because Bullet's version "seems to be broken", :44,464; this one is not)
+  // (the reference comments the AllVsAll count out, :44: its manifolds remember the contact distance they were created
+  // under, so the count depends on the history of SetContactDistance calls (:464 "seems to be broken").  The engine's
+  // AllVsAll is that of a checker whose distance was set before the first call: contacts up to 2.001 d, which leaves
+  // every count of this test as BodyVsAll's)
   checker->SetContactDistance(0);
   box1->SetTransform(Transform(Vector(1, 0, 0, 0), Vector(.9, 0, 0)));
   box0->SetTransform(Transform(Vector(1, 0, 0, 0), Vector(0, 0, 0)));
@@ -459,10 +462,34 @@ static void test_linearize(const string& in, const string& out) {
   fclose(f);
 }
 
+// CreateCollisionChecker's switch (TRAJOPT_COLLISION_CHECKER = hip | bullet): "bullet" and unknown names are errors, never a
+// silent substitute; unset / hip give the HIP checker.  The "bullet" and "unknown" cases need no GPU.
+static void test_factory_switch() {
+  EnvironmentBasePtr env(new EnvironmentBase);
+  const char* bad[2] = {"bullet", "fcl"};
+  for (int i = 0; i < 2; ++i) {
+    setenv("TRAJOPT_COLLISION_CHECKER", bad[i], 1);
+    bool threw = false;
+    try { CreateCollisionChecker(env); } catch (const std::runtime_error& e) { threw = string(e.what()).find(bad[i]) != string::npos; }
+    EXPECT_TRUE(threw);
+  }
+  unsetenv("TRAJOPT_COLLISION_CHECKER");
+}
+static void test_factory_hip() {
+  EnvironmentBasePtr env(new EnvironmentBase);
+  setenv("TRAJOPT_COLLISION_CHECKER", "hip", 1);
+  CollisionCheckerPtr a = CreateCollisionChecker(env);
+  unsetenv("TRAJOPT_COLLISION_CHECKER");
+  CollisionCheckerPtr b = CreateCollisionChecker(env);
+  EXPECT_TRUE(dynamic_cast<HIPCollisionChecker*>(a.get()) != NULL && dynamic_cast<HIPCollisionChecker*>(b.get()) != NULL);
+}
+
 int main(int argc, char** argv) {
   string cmd = argc > 1 ? argv[1] : "";
   try {
     if (cmd == "box_distance") test_box_distance();
+    else if (cmd == "factory_switch") test_factory_switch();
+    else if (cmd == "factory_hip") test_factory_hip();
     else if (cmd == "continuous_boxes") test_continuous_boxes();
     else if (cmd == "linearize" && argc == 4) test_linearize(argv[2], argv[3]);
     else { fprintf(stderr, "usage: host_unit box_distance | continuous_boxes | linearize IN OUT\n"); return 2; }

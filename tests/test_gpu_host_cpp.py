@@ -28,7 +28,7 @@ def _run(*args):
     return p.stdout
 
 
-@pytest.mark.parametrize("cmd", ["box_distance", "continuous_boxes"])
+@pytest.mark.parametrize("cmd", ["box_distance", "continuous_boxes", "factory_switch", "factory_hip"])
 def test_reference_unit_tests_through_the_cpp_host(built, cmd):
     assert "PASSED" in _run(cmd)
 

@@ -118,6 +118,10 @@ def test_random_scenes_vs_oracle_poses_api(eng, seed, spread):
                                       w.cast_vs_all(sets[k], robot, sets[k][robot], T1[k]), "cast set %d" % k)
         # the unit of the headline metric: both sides count the same pair evaluations (box-cull survivors)
         assert (pe_d, pe_c) == (c1 - c0, w.counter(0) - c1)
+        # AllVsAll (bullet_collision_checker.cpp:463-498): every unordered object pair once, contacts up to 2.001 d, values after the
+        # manifold round trip -- bit for bit against the oracle (itself checked against the reference's manifold walk on the CPU)
+        for k in (0, 1):
+            util.assert_same_contacts(util.records_to_contacts(eng.all_vs_all_poses(sets[k])), w.all_vs_all(sets[k]), "all-vs-all set %d" % k)
     w.close()
 
 

@@ -318,6 +318,29 @@ def test_epa_small_pools_then_full_pools_same_results(built, tmp_path):
     assert dll.emu_epa_redone() > 20, dll.emu_epa_redone()
 
 
+@pytest.mark.skipif(not B.ref_available(), reason="oracle/_ref/libref.so is only built where /root/reference exists")
+@pytest.mark.parametrize("seed", list(range(100, 106)) + list(range(300, 304)) + list(range(900, 906)))
+def test_all_vs_all_oracle_vs_reference_bullet_random(built, seed):
+    """AllVsAll on random worlds (boxes, hulls, cylinders, spheres, compounds on both sides): the oracle against the
+    reference's manifold walk, twice in a row (the reference clears its manifolds after every call).  A fresh reference
+    world per contact distance: its manifolds keep the breaking threshold they were created under."""
+    rng = np.random.default_rng(seed)
+    if seed >= 900:
+        s, objT, robot = synth.random_scene(rng, spread=0.35, round_prob=0.9, spheres=True, n_static=8, n_robot=6)
+    else:
+        s, objT, robot = synth.random_scene(rng, spread=float(rng.choice([0.3, 0.6])), round_prob=0.5 if seed >= 300 else 0.0)
+    n = 0
+    for d in (0.0, 0.09):
+        wr, wo = B.ref_world(s), B.oracle_world(s)
+        wr.set_contact_distance(d); wo.set_contact_distance(d)
+        for rep in range(2):
+            a, b = wo.all_vs_all(objT), wr.all_vs_all(objT)
+            util.assert_same_all_vs_all(a, b, "seed %d d %g" % (seed, d))
+            n += len(a)
+        wr.close(); wo.close()
+    assert n > 10
+
+
 @pytest.mark.parametrize("mk", WORLDS)
 def test_reference_continuous_check_known_answer(built, mk):
     """collision-checker-unit.cpp:102-120: boxbot swept from (-1.9, 0) to (0, 1.9) past the unit box at the origin:
@@ -593,3 +616,12 @@ def test_engine_fails_loudly_without_gpu(built):
         pytest.skip("a GPU is present")
     with pytest.raises(engine.EngineError):
         engine.Engine(0)
+
+
+def test_cpp_factory_switch_refuses_other_checkers(built):
+    """CreateCollisionChecker (the reference's one factory, bullet_collision_checker.cpp:1036-1039) with the switch
+    TRAJOPT_COLLISION_CHECKER: asking for `bullet` (not part of this build) or an unknown name throws -- no GPU needed."""
+    import subprocess
+    drv = os.path.join(ROOT, "tests", "cpp", "host_unit")
+    p = subprocess.run([drv, "factory_switch"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0 and "PASSED" in p.stdout, p.stdout + p.stderr

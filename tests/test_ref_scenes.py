@@ -49,6 +49,43 @@ def test_oracle_vs_reference_bullet_in_reference_scenes(built, name):
     wo.close(); wr.close()
 
 
+def _pose_of(rb, static_T, q):
+    link_obj = np.array(rb.link_obj)
+    have = link_obj >= 0
+    P = static_T.copy()
+    P[link_obj[have]] = B.oracle_fk(rb, q)[have]
+    return P
+
+
+@pytest.mark.skipif(not B.ref_available(), reason="oracle/_ref/libref.so is only built where /root/reference exists")
+@pytest.mark.parametrize("name", SCENES)
+def test_all_vs_all_oracle_vs_reference_bullet(built, name):
+    """AllVsAll (bullet_collision_checker.cpp:463-498): the oracle's restatement against the reference's
+    performDiscreteCollisionDetection + manifold walk (ref_driver.cpp: ref_all_vs_all), robot self pairs included:
+    contact set, manifold order of the two objects, distance / points / normal bit for bit, weight 1 / numContacts = 1
+    throughout, contacts beyond d (up to 2.001 d) present."""
+    s, rb, static_T = world(name)
+    trajs = util.benchmark_trajectories(rb, np.random.default_rng(1), 2)
+    wo, wr = B.oracle_world(s), B.ref_world(s)
+    for w in (wo, wr):
+        w.set_contact_distance(D)
+    # zero-state self collisions off, as trajopt does at set-up (collision_checker.cpp:41-56): asymmetric entries included
+    allowed = np.ones((s.n_objects, s.n_objects), np.uint8)
+    z = wo.links_vs_all(_pose_of(rb, static_T, np.zeros(rb.K)), list(range(s.n_objects)), mask=M.GROUP_ROBOT)
+    allowed[z["objA"], z["objB"]] = 0
+    for use_allowed in (False, True):
+        if use_allowed:
+            wo.set_allowed(allowed); wr.set_allowed(allowed)
+        for q in (trajs[0, 0], trajs[1, 5]):
+            P = _pose_of(rb, static_T, q)
+            a, b = wo.all_vs_all(P), wr.all_vs_all(P)
+            util.assert_same_all_vs_all(a, b, name)
+            assert len(a) > 50 and (a["dist"] > D).any() and (a["dist"] <= np.float32(2.001 * np.float32(D))).all()
+            pairs = list(zip(a["objA"].tolist(), a["childA"].tolist(), a["objB"].tolist(), a["childB"].tolist()))
+            assert len(pairs) == len(set(pairs))
+    wo.close(); wr.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", SCENES)
 def test_engine_vs_oracle_in_reference_scenes(built, name):
@@ -71,11 +108,15 @@ def test_engine_vs_oracle_in_reference_scenes(built, name):
             util.assert_same_linearization(rec[sel], g[sel], orec, og, "%s cast=%s b=%d" % (name, cast, b))
             total += len(orec)
     assert total > 0
-    # AllVsAll (bullet_collision_checker.cpp:463-498) in the robot's first pose: each unordered geometry pair once
-    cc.SetDOFValues(trajs[0, 0])
-    allc = []
-    cc.AllVsAll(allc)
-    keys = [(min((c.linkA, c.childA), (c.linkB, c.childB)), max((c.linkA, c.childA), (c.linkB, c.childB))) for c in allc]
-    assert len(keys) == len(set(keys))
+    # AllVsAll (bullet_collision_checker.cpp:463-498) in two poses: the engine against the oracle (which equals the reference's
+    # manifold walk, test_all_vs_all_oracle_vs_reference_bullet): contact set with child numbers, values bit for bit, weight 1
+    for q in (trajs[0, 0], trajs[1, 5]):
+        cc.SetDOFValues(q)
+        allc = []
+        cc.AllVsAll(allc)
+        assert all(c.weight == 1.0 for c in allc)
+        rec = cc.eng.all_vs_all_poses(cc._current_poses())
+        assert len(rec) == len(allc) > 50
+        util.assert_same_contacts(util.records_to_contacts(rec), w.all_vs_all(cc._current_poses()), "%s AllVsAll" % name)
     w.close()
     cc.eng.close()

@@ -158,16 +158,11 @@ class HIPCollisionChecker:
         self.LinksVsAll(body_links, collisions, filterMask)
 
     def AllVsAll(self, collisions):
-        """bullet_collision_checker.cpp:463-498 ("seems to be broken" upstream): every link against every other, each
-        unordered pair once, weight 1/numContacts = 1 (one contact per convex pair)."""
-        T = self._current_poses()
-        rec = self.eng.links_vs_all_poses(T, list(range(self.scene.n_objects)), -1)
-        seen = set()
-        for c in _collisions_from_records(rec):
-            k = (min(c.linkA, c.linkB), max(c.linkA, c.linkB), min(c.childA, c.childB), max(c.childA, c.childB))
-            if k not in seen:
-                seen.add(k)
-                collisions.append(c)
+        """bullet_collision_checker.cpp:463-498 ("seems to be broken" upstream): the points of Bullet's persistent manifolds
+        after performDiscreteCollisionDetection = every unordered link pair once, one contact per convex pair up to the
+        breaking threshold 2.001 d (not d), weight 1/numContacts = 1 (tohc_all_vs_all_poses)."""
+        rec = self.eng.all_vs_all_poses(self._current_poses())
+        collisions.extend(_collisions_from_records(rec))   # Collision.weight defaults to 1
 
     def CastVsAll(self, rad, links, startjoints, endjoints, collisions):
         dofs = np.stack([np.asarray(startjoints, float), np.asarray(endjoints, float)])

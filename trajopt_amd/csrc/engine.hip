@@ -1484,8 +1484,11 @@ int tohc_cast_vs_all_batch(tohc_engine *e, const double *dofs, int B, int T, int
   return rc;
 }
 
+// all_pairs: AllVsAll -- every unordered object pair once (the broadphase keeps X > Q), contacts kept up to the breaking
+// threshold 2.001 d instead of d (boxes and the pre-test's bound grown to match), the manifold round trip applied to the
+// fetched records
 static int posesQuery(tohc_engine *e, const double *obj_T, const double *cast_T1, int n_sets, const int32_t *query, int n_query, int filter_mask,
-                      int cast, const tohc_record **records, int *n_records) {
+                      int cast, const tohc_record **records, int *n_records, bool all_pairs = false) {
   if (!e) return TOHC_E_INVALID;
   if (!n_records) return fail(e, TOHC_E_INVALID, "n_records is null");
   *n_records = 0;
@@ -1517,8 +1520,9 @@ static int posesQuery(tohc_engine *e, const double *obj_T, const double *cast_T1
   HIPCHK(e->d_dynXf.reserve((size_t)n_sets * nch * 12)); HIPCHK(e->d_dynAabb.reserve((size_t)n_sets * nch * 6));
   DynMap dm = dynMapPoses(e);
   const size_t tot = (size_t)n_sets * nch;
+  const float keep = all_pairs ? e->breaking : e->d;
   hipLaunchKernelGGL(k_dyn_children, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, devScene(e), dm, e->d_objQT.p, n_sets,
-                     e->d, e->d_dynXf.p, e->d_dynAabb.p);
+                     keep, e->d_dynXf.p, e->d_dynAabb.p);
   std::vector<double> T1;
   if (cast) {
     // end-of-sweep poses: the query links move, everything else keeps its pose
@@ -1535,13 +1539,56 @@ static int posesQuery(tohc_engine *e, const double *obj_T, const double *cast_T1
   HIPCHK(hipStreamSynchronize(s));  // caller-owned / local host buffers may go away
   CallParams cp;
   memset(&cp, 0, sizeof cp);
-  cp.T = 1; cp.gap = 0; cp.cast = cast; cp.filter_mask = filter_mask; cp.want_jac = 0; cp.d = e->d; cp.breaking = e->breaking;
+  cp.T = 1; cp.gap = 0; cp.cast = cast; cp.filter_mask = filter_mask; cp.want_jac = 0; cp.d = keep; cp.breaking = e->breaking;
+  cp.ordered_pairs = all_pairs ? 1 : 0;
   cp.n_cast_sets = n_sets;
   e->last_sets = n_sets;
   rc = launchNarrow(e, dm, e->d_qchildrenP.p, qch, cp, false, slot, false);
   if (rc != TOHC_OK) return rc;
   const double *g = nullptr;
   return tohc_fetch(e, records, &g, n_records);
+}
+
+// AllVsAll (bullet_collision_checker.cpp:463-498) reads its contacts from Bullet's persistent manifolds, one per convex
+// pair, each fed one point by GJK: btManifoldResult::addContactPoint (btManifoldResult.cpp:85-126) stores the point in the
+// two OBJECTS' frames and refreshContactPoints (btPersistentManifold.cpp:199-259; own manifold,
+// btConvexConvexAlgorithm.cpp:583-586) derives the world points back from those and the distance as (posA - posB) . n.
+// Same fp32 steps here, on the fetched records (a few hundred of them: host code).
+int tohc_all_vs_all_poses(tohc_engine *e, const double *obj_T, const tohc_record **records, int *n_records) {
+  if (!e) return TOHC_E_INVALID;
+  if (!n_records) return fail(e, TOHC_E_INVALID, "n_records is null");
+  *n_records = 0;
+  if (!e->have_scene) return fail(e, TOHC_E_STATE, "upload the scene first");
+  std::vector<int32_t> query((size_t)e->n_objects);
+  std::iota(query.begin(), query.end(), 0);
+  const tohc_record *rec = nullptr;
+  int n = 0;
+  int rc = posesQuery(e, obj_T, nullptr, 1, query.data(), (int)query.size(), -1, 0, &rec, &n, true);
+  if (rc != TOHC_OK) return rc;
+  tohc_record *out = const_cast<tohc_record *>(rec);   // the engine's own host buffer
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    tohc_record r = rec[i];
+    // the manifold walk asks CanCollide again in the manifold's order of the two objects (:484); the broadphase asked at
+    // (lower, higher) object number like the near callback (:418) -- with one-directional exclusions both count
+    if (!e->h_allowed.empty() && !e->h_allowed[(size_t)r.idA * e->n_objects + r.idB]) continue;
+    const Xf tA = xfFrom7(obj_T + 7 * (size_t)r.idA), tB = xfFrom7(obj_T + 7 * (size_t)r.idB);
+    const V3 nW = mk((float)r.n[0], (float)r.n[1], (float)r.n[2]);
+    const V3 pointA = mk((float)r.ptA[0], (float)r.ptA[1], (float)r.ptA[2]), pointB = mk((float)r.ptB[0], (float)r.ptB[1], (float)r.ptB[2]);
+    const V3 localA = mulVM(pointA - tA.o, tA.b), localB = mulVM(pointB - tB.o, tB.b);   // btTransform::invXform
+    const V3 posA = xfApply(tA, localA), posB = xfApply(tB, localB);
+    const float dist = dot(posA - posB, nW);
+    if (!(dist <= e->breaking)) continue;   // validContactDistance
+    const V3 diff = posB - (posA - nW * dist);
+    if (dot(diff, diff) > e->breaking * e->breaking) continue;
+    r.dist = dist;
+    r.ptA[0] = posA.x, r.ptA[1] = posA.y, r.ptA[2] = posA.z;
+    r.ptB[0] = posB.x, r.ptB[1] = posB.y, r.ptB[2] = posB.z;
+    out[m++] = r;
+  }
+  if (records) *records = rec;
+  *n_records = m;
+  return TOHC_OK;
 }
 
 int tohc_links_vs_all_poses(tohc_engine *e, const double *obj_T, int n_sets, const int32_t *query, int n_query, int filter_mask,

@@ -117,6 +117,7 @@ struct CallParams {
   unsigned int seg_cap;      // capacity of ONE shard of the pair / EPA / hit queues
   unsigned int max_records;
   int dbg_max_iter;          // diagnostics only: 1000 = the reference's gGjkMaxIter
+  int ordered_pairs;         // AllVsAll: a query child meets only the children of objects with a higher number
   unsigned int epa_small_v, epa_small_f;   // k_tail_epa's first-attempt pools (<= TOHC_EPA_SMALL_V / _F; smaller only in tests)
 };
 
@@ -472,7 +473,8 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
         // discrete: contactTest skips the query object itself (btCollisionWorld.cpp:1132-1133).  Cast: the swept shape is a
         // temporary object that is not in the world, so nothing is skipped -- a query link whose own object passes the
         // KinBodyFilter mask (a grabbed body's link) meets its resting self, as in the reference (bcc:983, 886-892)
-        keep = (CAST || X != Q) && (CAST ? (gx & TOHC_GROUP_KINBODY) != 0 : (gx & (short)cp.filter_mask) != 0) && allowedRow[X] != 0;
+        keep = (CAST || X != Q) && (CAST ? (gx & TOHC_GROUP_KINBODY) != 0 : (gx & (short)cp.filter_mask) != 0) && allowedRow[X] != 0 &&
+               (!cp.ordered_pairs || X > Q);
       }
       ncand += (unsigned int)__popcll(__ballot(keep));
       if (ca.dbg == 1) keep = false;

@@ -79,6 +79,7 @@ SYMBOLS = {
                                           C.POINTER(C.c_int)]),
     "tohc_cast_vs_all_poses": (C.c_int, [C.c_void_p, _f64p, _f64p, C.c_int, _i32p, C.c_int, C.POINTER(C.c_void_p),
                                          C.POINTER(C.c_int)]),
+    "tohc_all_vs_all_poses": (C.c_int, [C.c_void_p, _f64p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "tohc_continuous_check_trajectory": (C.c_int, [C.c_void_p, _f64p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "tohc_continuous_check_poses": (C.c_int, [C.c_void_p, _f64p, C.c_int, _i32p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "tohc_forward_kinematics": (C.c_int, [C.c_void_p, _f64p, C.c_int, _f64p]),
@@ -277,6 +278,14 @@ class Engine:
         rec, n = C.c_void_p(), C.c_int()
         self._chk(self.lib.tohc_links_vs_all_poses(self.h, _p(obj_T, C.c_double), obj_T.shape[0], _p(q, C.c_int32), len(q),
                                                    int(filter_mask), C.byref(rec), C.byref(n)))
+        return self._collect(rec, None, n, 1, True)[0]
+
+    def all_vs_all_poses(self, obj_T):
+        """AllVsAll (bullet_collision_checker.cpp:463-498) at the given object poses: every unordered object pair once, contacts
+        up to 2.001 d, values after the manifold round trip; every record's weight is 1 (tohc_all_vs_all_poses)."""
+        obj_T = np.ascontiguousarray(obj_T, np.float64).reshape(self.n_objects, 7)
+        rec, n = C.c_void_p(), C.c_int()
+        self._chk(self.lib.tohc_all_vs_all_poses(self.h, _p(obj_T, C.c_double), C.byref(rec), C.byref(n)))
         return self._collect(rec, None, n, 1, True)[0]
 
     def cast_vs_all_poses(self, obj_T, query, T1):

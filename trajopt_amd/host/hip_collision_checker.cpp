@@ -415,18 +415,11 @@ void HIPCollisionChecker::AllVsAll(vector<Collision>& collisions) {   // :463-49
   UpdateFromRave();
   if (m_obj2link.empty()) return;
   vector<double> T = CurrentPoses();
-  vector<int32_t> query(m_obj2link.size());
-  for (size_t i = 0; i < query.size(); ++i) query[i] = (int32_t)i;
   const tohc_record* r;
   int n;
-  chk(tohc_links_vs_all_poses(m_e, T.data(), 1, query.data(), (int)query.size(), -1, &r, &n));
+  chk(tohc_all_vs_all_poses(m_e, T.data(), &r, &n));   // one manifold point per convex pair: weight 1. / numContacts = 1 (:487)
   ++m_engineCalls;
-  std::set<std::pair<std::pair<int, int>, std::pair<int, int> > > seen;   // each unordered geometry pair once; weight 1/numContacts = 1
-  for (int i = 0; i < n; ++i) {
-    std::pair<int, int> a(r[i].idA, r[i].childA), b(r[i].idB, r[i].childB);
-    if (b < a) std::swap(a, b);
-    if (seen.insert(std::make_pair(a, b)).second) collisions.push_back(ToCollision(r[i], NULL, 0));
-  }
+  for (int i = 0; i < n; ++i) collisions.push_back(ToCollision(r[i], NULL, 0));
 }
 
 void HIPCollisionChecker::CastVsAll(Configuration& rad, const vector<KinBody::LinkPtr>& links, const DblVec& startjoints, const DblVec& endjoints,
