@@ -112,7 +112,7 @@ struct tohc_engine {
   int n_statR = 0, n_stat_padR = 0, n_clR = 0, n_cl_padR = 0;
 
   // per-call buffers
-  DBuf<double> d_dofs, d_linkQT, d_objQT, d_objQT1, d_grads;
+  DBuf<double> d_dofs, d_linkQT, d_linkZ, d_objQT, d_objQT1, d_grads;
   DBuf<float> d_dynXf, d_dynAabb, d_dynXf1, d_dynAabb1;
   DBuf<float> d_rays;              // RayCastCollision: [n_rays][8]
   DBuf<unsigned int> d_ray_closest;
@@ -419,39 +419,43 @@ static int refreshStatic(tohc_engine *e) {
     HIPCHK(upload(e->d_stat_sph, cs, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
   }
-  // SoA cull-box table of the children that never move in robot mode (everything until a robot is uploaded), in
-  // Morton order of the box centres so that 64 consecutive entries are neighbours in space, + one box per 64 entries
+  // SoA cull-box table of the children that never move in robot mode (everything until a robot is uploaded), cut into
+  // clusters of 64 consecutive entries with one box per cluster.  The order is that of the leaves of a k-d split: the
+  // set is sorted along the longest axis of its box centres' bounds and cut so that the left part holds a multiple of 64
+  // entries (half of them, rounded up to whole clusters), recursively; every cluster but the very last is a full leaf.
+  // (Round 1 used 64 consecutive entries in Morton order of the centres: on config 4 a query box overlapped 2.8 of those
+  // cluster boxes on average, 1.0 of these -- each overlap is a 64-lane round of box tests in k_broadphase / k_sweep.
+  // Which children share a cluster never shows in the results.)
   std::vector<int> st = e->h_stat_childrenR;
   e->n_statR = (int)st.size();
   {
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int c : st)
+    std::vector<float> ctr(3 * st.size());
+    for (size_t i = 0; i < st.size(); ++i)
       for (int k = 0; k < 3; ++k) {
-        float m = 0.5f * (bb[6 * (size_t)c + k] + bb[6 * (size_t)c + 3 + k]);
-        lo[k] = std::min(lo[k], m); hi[k] = std::max(hi[k], m);
+        float m = 0.5f * (bb[6 * (size_t)st[i] + k] + bb[6 * (size_t)st[i] + 3 + k]);
+        ctr[3 * i + k] = m == m ? m : 0.f;   // (NaN poses: anywhere will do, their boxes overlap nothing)
       }
-    auto spread = [](uint32_t v) {  // 10 bits -> every third bit
-      v &= 1023u;
-      v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu;
-      v = (v | (v << 4)) & 0x030C30C3u;  v = (v | (v << 2)) & 0x09249249u;
-      return v;
-    };
-    std::vector<std::pair<uint32_t, int>> keyed;
-    keyed.reserve(st.size());
-    for (int c : st) {
-      uint32_t code = 0;
-      for (int k = 0; k < 3; ++k) {
-        float m = 0.5f * (bb[6 * (size_t)c + k] + bb[6 * (size_t)c + 3 + k]);
-        float ext = hi[k] - lo[k];
-        float u = ext > 0 ? (m - lo[k]) / ext : 0.f;
-        if (!(u >= 0.f)) u = 0.f;   // also catches NaN
-        if (u > 1.f) u = 1.f;
-        code |= spread((uint32_t)(u * 1023.f)) << k;
-      }
-      keyed.push_back(std::make_pair(code, c));
+    std::vector<int> ord(st.size());
+    std::iota(ord.begin(), ord.end(), 0);
+    std::vector<std::pair<size_t, size_t>> todo(1, std::make_pair((size_t)0, st.size()));
+    while (!todo.empty()) {
+      const size_t b = todo.back().first, n = todo.back().second;
+      todo.pop_back();
+      if (n <= 64) continue;
+      float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      for (size_t i = b; i < b + n; ++i)
+        for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], ctr[3 * ord[i] + k]); hi[k] = std::max(hi[k], ctr[3 * ord[i] + k]); }
+      int ax = 0;
+      if (hi[1] - lo[1] > hi[ax] - lo[ax]) ax = 1;
+      if (hi[2] - lo[2] > hi[ax] - lo[ax]) ax = 2;
+      std::sort(ord.begin() + b, ord.begin() + b + n, [&](int x, int y) { return ctr[3 * x + ax] < ctr[3 * y + ax] || (ctr[3 * x + ax] == ctr[3 * y + ax] && x < y); });
+      const size_t nl = (n + 127) / 128 * 64;
+      todo.push_back(std::make_pair(b, nl));
+      todo.push_back(std::make_pair(b + nl, n - nl));
     }
-    std::sort(keyed.begin(), keyed.end());
-    for (size_t i = 0; i < st.size(); ++i) st[i] = keyed[i].second;
+    std::vector<int> sorted(st.size());
+    for (size_t i = 0; i < st.size(); ++i) sorted[i] = st[ord[i]];
+    st.swap(sorted);
   }
   e->n_clR = (e->n_statR + 63) / 64;
   e->n_stat_padR = std::max(e->n_clR, 1) * 64;
@@ -1058,6 +1062,7 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
   a.sc = devScene(e); a.dm = dm; a.rb = devRobot(e); a.cp = cp;
   a.dynXf0 = e->d_dynXf.p; a.dynXf1 = sep1 ? e->d_dynXf1.p : e->d_dynXf.p;
   a.linkQT = robotMode ? e->d_linkQT.p : nullptr;
+  a.linkZ = robotMode ? e->d_linkZ.p : nullptr;
   a.dofs = robotMode ? e->d_dofs.p : nullptr;
   a.pairs = ln.pairs.p; a.epaq = ln.epaq.p; a.penq = ln.penq.p; a.hits = ln.hits.p; a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p; a.rec_base = e->d_rec_base.p + slot;
   a.records = e->d_records.p; a.grads = e->d_grads.p; a.dbg = e->d_dbg.p;
@@ -1193,6 +1198,7 @@ int tohc_stage_dofs(tohc_engine *e, const double *dofs, int B, int T) {
   HIPCHK(e->d_dofs.reserve(n_sets * e->K));
   HIPCHK(hipMemcpyAsync(e->d_dofs.p, e->h_dofs.p, n_sets * e->K * sizeof(double), hipMemcpyHostToDevice, e->stream));
   HIPCHK(e->d_linkQT.reserve(n_sets * e->n_links * 7));
+  HIPCHK(e->d_linkZ.reserve(n_sets * e->n_links * 3));
   HIPCHK(e->d_objQT.reserve(n_sets * std::max(e->n_dyn_objR, 1) * 7));
   HIPCHK(e->d_dynXf.reserve(n_sets * std::max(e->n_dyn_childrenR, 1) * 12));
   HIPCHK(e->d_dynAabb.reserve(n_sets * std::max(e->n_dyn_childrenR, 1) * 6));
@@ -1220,7 +1226,7 @@ static int enqueueRobot(tohc_engine *e, int gap, int cast, int filter_mask, int 
     for (auto &ln : e->lane) HIPCHK(hipStreamWaitEvent(s, ln.done, 0));   // pending enqueues still read the tables
     HIPCHK(hipEventRecord(ev[0], s));
     hipLaunchKernelGGL(k_fk, dim3((unsigned)n_sets), dim3(64), (size_t)e->n_links * 7 * sizeof(double), s, devRobot(e), devScene(e), dm, e->d_dofs.p,
-                       (int)n_sets, e->d, e->d_linkQT.p, e->d_objQT.p, e->d_dynXf.p, e->d_dynAabb.p);
+                       (int)n_sets, e->d, e->d_linkQT.p, e->d_objQT.p, e->d_dynXf.p, e->d_dynAabb.p, e->d_linkZ.p);
     HIPCHK(hipEventRecord(ev[1], s));
     HIPCHK(hipEventRecord(e->ev_fk, s));
     e->fk_done = true;

@@ -177,7 +177,7 @@ __device__ __forceinline__ unsigned int qlocate(const QPrefix &p, unsigned int s
 // -----------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_fk(DevRobot rb, DevScene sc, DynMap dm, const double *__restrict__ dofs, int n_cfg, float d,
                                            double *__restrict__ linkQT, double *__restrict__ objQT, float *__restrict__ dynXf,
-                                           float *__restrict__ dynAabb) {
+                                           float *__restrict__ dynAabb, double *__restrict__ linkZ = nullptr) {
   extern __shared__ double s_motion[];  // [n_links][7]
   const int s = blockIdx.x;
   if (s >= n_cfg) return;
@@ -228,6 +228,11 @@ __global__ void __launch_bounds__(64) k_fk(DevRobot rb, DevScene sc, DynMap dm, 
     dxfTo7(t, t7);
     double *out = linkQT + ((size_t)s * rb.n_links + i) * 7;
     for (int k = 0; k < 7; ++k) out[k] = t7[k];
+    if (linkZ) {   // the joint axis in the world, once per (configuration, link) instead of once per contact and joint (k_finish)
+      const D3 z = qrot(t.q, mkd(rb.axis[3 * i], rb.axis[3 * i + 1], rb.axis[3 * i + 2]));
+      double *oz = linkZ + ((size_t)s * rb.n_links + i) * 3;
+      oz[0] = z.x; oz[1] = z.y; oz[2] = z.z;
+    }
     const int slot = rb.link_dyn[i];
     if (objQT && slot >= 0) {
       double *oo = objQT + ((size_t)s * dm.n_dyn_obj + slot) * 7;
@@ -329,6 +334,7 @@ struct NarrowArgs {
   CallParams cp;
   const float *dynXf0, *dynXf1;
   const double *linkQT;   // [n_sets][n_links][7], null in poses mode
+  const double *linkZ;    // [n_sets][n_links][3]: every link's joint axis in the world (k_fk), null in poses mode
   const double *dofs;     // [n_sets][K]
   PairRec *pairs;
   EpaRec *epaq;
@@ -1185,16 +1191,16 @@ __device__ __forceinline__ double linearizeAt(const NarrowArgs &a, int set, int 
 // linearizeAt's: with at most one joint per column (DevRobot.fast_jac) a column's J is 0 + mult*col, exactly.
 // row: [2][TOHC_FAST_JAC_MAXK] doubles of the group (A's then B's contributions).
 template <int G>
-__device__ __forceinline__ void jacRow(const DevRobot &rb, const double *linkQT, int link, D3 n, D3 p, double *row) {
+__device__ __forceinline__ void jacRow(const DevRobot &rb, const double *linkQT, const double *linkZ, int link, D3 n, D3 p, double *row) {
   const int gl = Grp<G>::lane();
   const int c0 = rb.chain_off[link], c1 = rb.chain_off[link + 1];
   for (int c = c0 + gl; c < c1; c += G) {
     const int i = rb.chain[c];
     const int k = rb.dof_col[i];
     if (rb.jtype[i] == TOHC_J_FIXED || k < 0 || k >= rb.n_joint_inds) continue;
-    Dxf t = dxfFrom7(linkQT + 7 * i);
-    D3 z = qrot(t.q, mkd(rb.axis[3 * i], rb.axis[3 * i + 1], rb.axis[3 * i + 2]));
-    D3 col = rb.jtype[i] == TOHC_J_REVOLUTE ? cross(z, p - t.t) : z;
+    const double *tq = linkQT + 7 * i, *zq = linkZ + 3 * i;
+    const D3 z = mkd(zq[0], zq[1], zq[2]);   // = qrot(link pose, axis), bit for bit: k_fk does that product
+    D3 col = rb.jtype[i] == TOHC_J_REVOLUTE ? cross(z, p - mkd(tq[4], tq[5], tq[6])) : z;
     D3 J = mkd(0, 0, 0);
     J.x += rb.mult[i] * col.x; J.y += rb.mult[i] * col.y; J.z += rb.mult[i] * col.z;
     row[k] = n.x * J.x + n.y * J.y + n.z * J.z;
@@ -1206,6 +1212,7 @@ __device__ __forceinline__ double linearizeFast(const NarrowArgs &a, int set, in
   const DevRobot &rb = a.rb;
   const int gl = Grp<G>::lane();
   const double *linkQT = a.linkQT + (size_t)set * rb.n_links * 7;
+  const double *linkZ = a.linkZ + (size_t)set * rb.n_links * 3;
   const double *q = a.dofs + (size_t)set * rb.K;
   double *rowA = row, *rowB = row + TOHC_FAST_JAC_MAXK;
   for (int k = gl; k < rb.K; k += G) {
@@ -1217,8 +1224,8 @@ __device__ __forceinline__ double linearizeFast(const NarrowArgs &a, int set, in
     rowA[k] = va; rowB[k] = vb;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the group's lanes share one wavefront: LDS ops are in order
-  if (la >= 0) jacRow<G>(rb, linkQT, la, n, ptA, rowA);
-  if (lb >= 0) jacRow<G>(rb, linkQT, lb, n, ptB, rowB);
+  if (la >= 0) jacRow<G>(rb, linkQT, linkZ, la, n, ptA, rowA);
+  if (lb >= 0) jacRow<G>(rb, linkQT, linkZ, lb, n, ptB, rowB);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   for (int k = gl; k < rb.K; k += G) {
     double g = 0;
