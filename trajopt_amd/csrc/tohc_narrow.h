@@ -66,6 +66,14 @@ struct Grp {
     int oi = __builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, false);
     combineHi(v, i, ov, oi);
   }
+  // does any lane of the group say so?  (every lane of the group must be active)
+  static TOHC_DEV bool any(bool p) {
+    const unsigned long long b = __ballot(p);
+    if (G >= 64) return b != 0;
+    const unsigned base = (unsigned)(threadIdx.x & 63) & ~(unsigned)(G - 1);
+    return ((b >> base) & ((1ull << (G & 63)) - 1ull)) != 0;
+  }
+  static TOHC_DEV void fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }   // LDS written by one lane, read by another of the wavefront
   static TOHC_DEV void argmax_hi(float &v, int &i) {
     if (G >= 2) dppStepHi<0xB1>(v, i);
     if (G >= 4) dppStepHi<0x4E>(v, i);
@@ -79,6 +87,8 @@ struct Grp {
   static float bcast(float v, int) { return v; }
   static void argmax(float &, int &) {}
   static void argmax_hi(float &, int &) {}
+  static bool any(bool p) { return p; }
+  static void fence() {}
 #endif
 };
 
@@ -89,6 +99,8 @@ struct Grp<1> {  // one lane per pair: nothing to exchange
   static TOHC_DEV float bcast(float v, int) { return v; }
   static TOHC_DEV void argmax(float &, int &) {}
   static TOHC_DEV void argmax_hi(float &, int &) {}
+  static TOHC_DEV bool any(bool p) { return p; }
+  static TOHC_DEV void fence() {}
 };
 #endif
 
@@ -654,7 +666,7 @@ TOHC_DEV void gjkMain(const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &
 // its whole length again at the end of the kernel, so the pools are as large as the occupancy the registers give
 // (8 wavefronts per CU, 8 groups each: 160 KB / 64 = 2.5 KB) lets them be.
 #ifndef TOHC_EPA_SMALL_V
-#define TOHC_EPA_SMALL_V 24
+#define TOHC_EPA_SMALL_V 23   // (23 / 48: 2544 B, eight of them in 160 KB / 8 blocks per CU)
 #define TOHC_EPA_SMALL_F 48
 #endif
 #define TOHC_NIL 255
@@ -676,6 +688,7 @@ struct alignas(16) EpaMemT {
   uint32_t fe[NF];       // bytes: e[0] e[1] e[2] -
   uint16_t fstamp[NF];   // order of arrival on the hull (the reference's hull list is newest-first)
   uint16_t stk[NF];      // expand() stack: face | edge << 8 | stage << 10
+  uint16_t hz[NF];       // the horizon of one expansion, in visiting order: face | edge << 7 | new face's slot << 9
   // GJK2 simplices
   uint8_t sc[2][4];
   float sp[2][4];
@@ -1008,7 +1021,9 @@ struct Epa {
   unsigned stamp;
   EpaProf prof;
   // horizon
-  unsigned hcf, hff, hnf;
+  unsigned hnf;     // horizon edges met by this iteration's expansions (m->hz)
+  unsigned avail;   // free face slots as the reference's expand would find them at this point of the traversal: every face
+                    // it has removed so far is free again, every horizon edge met so far has taken one
 
   TOHC_DEV V3 svW(unsigned sv) const { return ld3(m->svw[sv]); }
   static TOHC_DEV unsigned byteOf(uint32_t w, unsigned k) { return (w >> (8 * k)) & 255u; }
@@ -1113,8 +1128,16 @@ struct Epa {
     if (bkey < 0) return hullLo ? (unsigned)__builtin_ctzll(hullLo) : 64u + (unsigned)__builtin_ctzll(hullHi);
     return (unsigned)(bkey & 255);
   }
-  // expand [epa:794-827] on an explicit stack (stage 0: entry, 1: first child returned, 2: second child returned)
-  TOHC_DEV bool expand(unsigned pass, unsigned w, unsigned f0, unsigned e0) {
+  // expand [epa:794-827] in two phases.  The reference's recursion makes each new face the moment it meets a horizon
+  // edge; nothing it does afterwards in the same iteration reads a new face (the traversal walks visible faces and
+  // tests the faces beyond the horizon, new faces hang off the far side of horizon edges), so here
+  //   traverse():    the same walk on an explicit stack (stage 0: entry, 1: first child returned, 2: second child
+  //                  returned) only NOTES the horizon edges, in visiting order, and counts the free slots exactly as
+  //                  the reference would find them (avail) -- running out of faces is detected at the same edge;
+  //   makeHorizon(): makes all the new faces at once, one lane per face, and binds the fan.
+  // A failure the reference meets half way (degenerate / non-convex new face, out of faces, a face reached twice) ends
+  // its iteration with what it had before (E_INVALIDHULL: the result is the previous best face), and it does here.
+  TOHC_DEV bool traverse(unsigned pass, unsigned w, unsigned f0, unsigned e0) {
     int sp = 1;
     bool ret = false;
     m->stk[0] = (uint16_t)(f0 | (e0 << 8));
@@ -1130,15 +1153,15 @@ struct Epa {
         const float nx = nd[0], ny = nd[1], nz = nd[2], fd = nd[3];
         if ((cp >> 24) != pass) {
           if ((dot(mk(nx, ny, nz), ww) - fd) < -0.00001f) {
-            unsigned nf = newface(byteOf(cp, e1), byteOf(cp, e), w, false);
-            if (nf != TOHC_NIL) {
-              bind(nf, 0, f, e);
-              if (hcf != TOHC_NIL) bind(hcf, 1, nf, 2); else hff = nf;
-              hcf = nf;
-              ++hnf;
+            if (avail != 0) {   // newface [epa:801] would find a slot
+              --avail;
+              m->hz[hnf++] = (uint16_t)(f | (e << 7));   // (hnf <= the pool's faces: each entry has taken a free slot)
               ret = true;
-            } else
+            } else {
+              status = E_OUTOFFACES;
+              if (limF < TOHC_EPA_MAX_FACES) exhausted = true;
               ret = false;
+            }
             --sp;
           } else {
             ((uint8_t *)&m->fcp[f])[3] = (uint8_t)pass;
@@ -1164,6 +1187,7 @@ struct Epa {
       } else {
         if (ret) {
           hullToStock(f);
+          ++avail;
           ret = true;
         } else
           ret = false;
@@ -1171,6 +1195,57 @@ struct Epa {
       }
     }
     return ret;
+  }
+  // The fan of new faces over the horizon m->hz[0 .. hnf), w = the new vertex: face k = (c[e+1], c[e], w) of horizon
+  // entry k [epa:801], bound to the face beyond its edge [epa:804], to its neighbours in the fan [epa:805] and round the
+  // end [epa:672]; arrival stamps in horizon order, as the reference's appends.  One lane per new face.
+  TOHC_DEV bool makeHorizon(unsigned w) {
+    const unsigned n = hnf, stamp0 = stamp;
+    // slots: the lowest free ones (which slot a face gets is invisible in the results)
+    for (unsigned k = 0; k < n; ++k) {
+      unsigned face;
+      if (freeLo) { face = (unsigned)__builtin_ctzll(freeLo); freeLo &= freeLo - 1; hullLo |= 1ull << face; }
+      else { face = (unsigned)__builtin_ctzll(freeHi); freeHi &= freeHi - 1; hullHi |= 1ull << face; face += 64u; }
+      m->hz[k] = (uint16_t)((m->hz[k] & 511u) | (face << 9));   // (every lane of the group writes the same value)
+#if defined(TOHC_EPA_PROF) && defined(__HIPCC__)
+      if (face > prof.maxface) prof.maxface = face;
+#endif
+    }
+    hullCount += n;
+    stamp += n;
+    Grp<G>::fence();
+    const V3 cw = svW(w);
+    bool bad = false;
+    int st = status;
+    for (unsigned k = (unsigned)Grp<G>::lane(); k < n; k += G) {
+      const unsigned hk = m->hz[k], hn = m->hz[k + 1 < n ? k + 1 : 0], hp = m->hz[k ? k - 1 : n - 1];
+      const unsigned f = hk & 127u, e = (hk >> 7) & 3u, face = hk >> 9;
+      const uint32_t cp = m->fcp[f];
+      const unsigned a = byteOf(cp, (e + 1) % 3), b = byteOf(cp, e);
+      m->fcp[face] = a | (b << 8) | (w << 16);   // pass = 0
+      m->fstamp[face] = (uint16_t)(stamp0 + k + 1);
+      m->ff[face] = f | ((hn >> 9) << 8) | ((hp >> 9) << 16);   // bind(nf, 0, f, e); bind(nf, 1, next, 2); bind(prev, 1, nf, 2)
+      m->fe[face] = e | (2u << 8) | (1u << 16);
+      ((uint8_t *)&m->ff[f])[e] = (uint8_t)face;
+      ((uint8_t *)&m->fe[f])[e] = 0;
+      // newface [epa:734-778], not forced
+      const V3 aw = svW(a), bw = svW(b);
+      V3 nrm = cross(bw - aw, cw - aw);
+      const float l = len(nrm);
+      if (l > 0.0001f) {
+        float d;
+        if (!(getedgedist(nrm, aw, bw, d) || getedgedist(nrm, bw, cw, d) || getedgedist(nrm, cw, aw, d))) d = dot(aw, nrm) / l;
+        nrm = vdiv(nrm, l);
+        float *o = m->fnd[face];
+        o[0] = nrm.x; o[1] = nrm.y; o[2] = nrm.z; o[3] = d;
+        if (!(d >= -0.00001f)) { bad = true; st = E_NONCONVEX; }
+      } else {
+        bad = true; st = E_DEGENERATED;
+      }
+    }
+    Grp<G>::fence();
+    if (Grp<G>::any(bad)) { status = bad ? st : E_NONCONVEX; return false; }   // (the caller ends the run: E_INVALIDHULL)
+    return true;
   }
 
   TOHC_DEV int evaluate(Gjk2<G, MEM> &g, V3 guess) {  // [epa:594-697]
@@ -1209,7 +1284,8 @@ struct Epa {
         status = E_VALID;
         for (; iterations < 255; ++iterations) {
           if (nextsv < limV) {
-            hcf = TOHC_NIL; hff = TOHC_NIL; hnf = 0;
+            hnf = 0;
+            avail = (unsigned)(__builtin_popcountll(freeLo) + __builtin_popcountll(freeHi));
             unsigned w = 4 + nextsv++;
             bool valid = true;
             ((uint8_t *)&m->fcp[best])[3] = (uint8_t)(++pass);
@@ -1224,10 +1300,10 @@ struct Epa {
               TOHC_PROF_T0(te);
               // best's own adjacency is not rewritten while its neighbours are expanded (binds touch the new faces
               // and the faces beyond the horizon), so the words read above stay current
-              for (unsigned j = 0; (j < 3) && valid; ++j) valid &= expand(pass, w, byteOf(bfw, j), byteOf(bew, j));
+              for (unsigned j = 0; (j < 3) && valid; ++j) valid &= traverse(pass, w, byteOf(bfw, j), byteOf(bew, j));
+              if (valid && (hnf >= 3)) valid = makeHorizon(w);
               TOHC_PROF_ACC(prof, 2, te);
               if (valid && (hnf >= 3)) {
-                bind(hcf, 1, hff, 2);
                 hullToStock(best);
                 TOHC_PROF_T0(tf);
                 best = findbest();
