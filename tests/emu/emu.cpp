@@ -91,6 +91,16 @@ bool pairEval(World *w, const Cvx<1> &A, const Xf &tA, const Cvx<1> &B, const Xf
       }
     }
     gjkFinishTail(isValid2, sep, tmpA, tmpB, st);
+    if (const char *lg = getenv("EMU_EPA_LOG")) {   // diagnostics: what an EPA run's length depends on
+      static FILE *f = fopen(lg, "w");
+      static long prevIt = 0, prevCalls = 0;
+      const EmuStats &es = emuStats();
+      V3 dir = tA.o - tB.o, ww;
+      float ov = 0;
+      if (len2(dir) > 1e-12f) { dir = vdiv(dir, len(dir)); sepAxisBeyond<1>(A, B, tA, tB, dir, 0.f, ww); ov = -dot(dir, ww); }
+      if (es.epa_calls != prevCalls) fprintf(f, "%ld %d %d %d %d %g %g\n", es.epa_iters - prevIt, A.kind, A.n, B.kind, B.n, (double)st.distance, (double)ov), fflush(f);
+      prevIt = es.epa_iters; prevCalls = es.epa_calls;
+    }
   }
   PairOut o;
   gjkOutput(st, md, o);

@@ -935,6 +935,9 @@ static int64_t countAabbTests(const tohc_engine *e, const std::vector<int> &qchi
 #ifndef TOHC_EPA_G
 #define TOHC_EPA_G 8   // lanes per pair in k_tail_epa (8 pairs per wavefront on the small pools: measured 0.45 ms per launch against 0.67 for 16 lanes on the full pools)
 #endif
+#ifndef TOHC_FINISH_G
+#define TOHC_FINISH_G 4   // lanes per hit in k_finish: most of a hit's work is the same for every lane of its group (measured per launch: 16 lanes 0.38 ms, 8: 0.29, 4: 0.22, 2: 0.23, 1: 0.20 but 73 KB of LDS rows per block at K = 18)
+#endif
 #ifndef TOHC_FINISH_BLOCKS_PER_CU
 #define TOHC_FINISH_BLOCKS_PER_CU 4   // with TOHC_FINISH_WAVES 4 (128 VGPRs): four waves per SIMD = 4 blocks of 256 per CU (measured: 2 -> 3 blocks +5 %, 4 / 4 another +3 %)
 #endif
@@ -998,8 +1001,9 @@ static int launchTail(tohc_engine *e) {
     HIPCHK(hipStreamWaitEvent(ln.stream, e->tail_ranged, 0));
     HIPCHK(hipEventRecord(ev[7], ln.stream));
     if (!h.empty) {
-      if (e->group == 64) hipLaunchKernelGGL((k_finish<64>), dim3(256 * 2), dim3(256), 0, ln.stream, h.a);
-      else hipLaunchKernelGGL((k_finish<16>), dim3(256 * TOHC_FINISH_BLOCKS_PER_CU), dim3(256), 0, ln.stream, h.a);
+      const int Kr = std::max(h.a.rb.K, 1);   // LDS: one pair of gradient rows per group
+      if (e->group == 64) hipLaunchKernelGGL((k_finish<64>), dim3(256 * 2), dim3(256), (size_t)(256 / 64) * 2 * Kr * sizeof(double), ln.stream, h.a);
+      else hipLaunchKernelGGL((k_finish<TOHC_FINISH_G>), dim3(256 * TOHC_FINISH_BLOCKS_PER_CU), dim3(256), (size_t)(256 / TOHC_FINISH_G) * 2 * Kr * sizeof(double), ln.stream, h.a);
     }
     HIPCHK(hipEventRecord(ev[8], ln.stream));
     HIPCHK(hipEventRecord(ln.done, ln.stream));

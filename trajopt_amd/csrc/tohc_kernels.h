@@ -1189,7 +1189,7 @@ __device__ __forceinline__ double linearizeAt(const NarrowArgs &a, int set, int 
 // joint's record and pose (independent loads, one round trip for the whole chain instead of a pointer chase per
 // column) and, if the joint moves an optimisation column, leaves n . J[column] in the group's LDS row.  Values equal
 // linearizeAt's: with at most one joint per column (DevRobot.fast_jac) a column's J is 0 + mult*col, exactly.
-// row: [2][TOHC_FAST_JAC_MAXK] doubles of the group (A's then B's contributions).
+// row: [2][K] doubles of the group (A's then B's contributions).
 template <int G>
 __device__ __forceinline__ void jacRow(const DevRobot &rb, const double *linkQT, const double *linkZ, int link, D3 n, D3 p, double *row) {
   const int gl = Grp<G>::lane();
@@ -1214,7 +1214,7 @@ __device__ __forceinline__ double linearizeFast(const NarrowArgs &a, int set, in
   const double *linkQT = a.linkQT + (size_t)set * rb.n_links * 7;
   const double *linkZ = a.linkZ + (size_t)set * rb.n_links * 3;
   const double *q = a.dofs + (size_t)set * rb.K;
-  double *rowA = row, *rowB = row + TOHC_FAST_JAC_MAXK;
+  double *rowA = row, *rowB = row + rb.K;
   for (int k = gl; k < rb.K; k += G) {
     double va = 0, vb = 0;
     if (k >= rb.n_joint_inds) {  // affine columns: no chain involved
@@ -1248,8 +1248,8 @@ template <int G>
 #define TOHC_FINISH_WAVES 4
 #endif
 __global__ void __launch_bounds__(256, TOHC_FINISH_WAVES) k_finish(NarrowArgs a) {
-  __shared__ double s_rows[256 / G][2 * TOHC_FAST_JAC_MAXK];
-  double *row = s_rows[threadIdx.x / G];
+  extern __shared__ double s_rows[];   // [256 / G][2][K]: the groups' gradient rows (launch: finishLds)
+  double *row = s_rows + (size_t)(threadIdx.x / G) * 2 * a.rb.K;
   const bool fast = a.rb.fast_jac != 0;
   const int groupsPerBlock = 256 / G;
   const unsigned int gid = blockIdx.x * groupsPerBlock + threadIdx.x / G;
