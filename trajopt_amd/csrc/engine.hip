@@ -114,6 +114,7 @@ struct tohc_engine {
   // per-call buffers
   DBuf<double> d_dofs, d_linkQT, d_linkZ, d_objQT, d_objQT1, d_grads;
   DBuf<float> d_dynXf, d_dynAabb, d_dynXf1, d_dynAabb1;
+  DBuf<CullSph> d_dynSph;   // [n_sets][moving children]: world bounding spheres at the first pose of each set (k_fk / k_dyn_children)
   DBuf<float> d_rays;              // RayCastCollision: [n_rays][8]
   DBuf<unsigned int> d_ray_closest;
   // Enqueues alternate between NLANE lanes, each with its own HIP stream and queues, so that the discrete and the
@@ -1076,6 +1077,7 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
     CullArgs ca;
     ca.a = a; ca.qchildren = d_qchildren; ca.nQ = nQ;
     ca.dynAabb0 = e->d_dynAabb.p; ca.dynAabb1 = sep1 ? e->d_dynAabb1.p : e->d_dynAabb.p;
+    ca.dynSph0 = e->d_dynSph.p;
     ca.pretest = e->pretest;
     ca.dbg = getenv("TOHC_BP_DBG") ? atoi(getenv("TOHC_BP_DBG")) : 0;
     if (cp.cast) hipLaunchKernelGGL((k_broadphase<true>), dim3((unsigned)blocks), dim3(TOHC_BP_THREADS), 0, s, ca);
@@ -1206,6 +1208,7 @@ int tohc_stage_dofs(tohc_engine *e, const double *dofs, int B, int T) {
   HIPCHK(e->d_objQT.reserve(n_sets * std::max(e->n_dyn_objR, 1) * 7));
   HIPCHK(e->d_dynXf.reserve(n_sets * std::max(e->n_dyn_childrenR, 1) * 12));
   HIPCHK(e->d_dynAabb.reserve(n_sets * std::max(e->n_dyn_childrenR, 1) * 6));
+  HIPCHK(e->d_dynSph.reserve(n_sets * std::max(e->n_dyn_childrenR, 1)));
   e->staged_B = B; e->staged_T = T; e->staged = true;   // (the caller's buffer has been copied; FK follows on the same stream)
   return TOHC_OK;
 }
@@ -1230,7 +1233,7 @@ static int enqueueRobot(tohc_engine *e, int gap, int cast, int filter_mask, int 
     for (auto &ln : e->lane) HIPCHK(hipStreamWaitEvent(s, ln.done, 0));   // pending enqueues still read the tables
     HIPCHK(hipEventRecord(ev[0], s));
     hipLaunchKernelGGL(k_fk, dim3((unsigned)n_sets), dim3(64), (size_t)e->n_links * 7 * sizeof(double), s, devRobot(e), devScene(e), dm, e->d_dofs.p,
-                       (int)n_sets, e->d, e->d_linkQT.p, e->d_objQT.p, e->d_dynXf.p, e->d_dynAabb.p, e->d_linkZ.p);
+                       (int)n_sets, e->d, e->d_linkQT.p, e->d_objQT.p, e->d_dynXf.p, e->d_dynAabb.p, e->d_linkZ.p, e->d_dynSph.p);
     HIPCHK(hipEventRecord(ev[1], s));
     HIPCHK(hipEventRecord(e->ev_fk, s));
     e->fk_done = true;
@@ -1528,11 +1531,12 @@ static int posesQuery(tohc_engine *e, const double *obj_T, const double *cast_T1
   e->h_qinfoP = queryInfo(e, qch, e->h_child_dynP);
   HIPCHK(upload(e->d_qchildrenP, e->h_qinfoP, s));
   HIPCHK(e->d_dynXf.reserve((size_t)n_sets * nch * 12)); HIPCHK(e->d_dynAabb.reserve((size_t)n_sets * nch * 6));
+  HIPCHK(e->d_dynSph.reserve((size_t)n_sets * nch));
   DynMap dm = dynMapPoses(e);
   const size_t tot = (size_t)n_sets * nch;
   const float keep = all_pairs ? e->breaking : e->d;
   hipLaunchKernelGGL(k_dyn_children, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, devScene(e), dm, e->d_objQT.p, n_sets,
-                     keep, e->d_dynXf.p, e->d_dynAabb.p);
+                     keep, e->d_dynXf.p, e->d_dynAabb.p, e->d_dynSph.p);
   std::vector<double> T1;
   if (cast) {
     // end-of-sweep poses: the query links move, everything else keeps its pose

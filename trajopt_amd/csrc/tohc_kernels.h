@@ -171,13 +171,24 @@ __device__ __forceinline__ unsigned int qlocate(const QPrefix &p, unsigned int s
   return sh * segCap + (i - st);
 }
 
+// the sphere stage of k_broadphase's pre-test for a child that moves: what CullSph holds for one that never does, at this pose
+__device__ __forceinline__ CullSph movingSph(const DevScene &sc, int child, const Xf &T) {
+  const ChildDesc *dd = sc.child_desc + child;
+  const F4 sl = *reinterpret_cast<const F4 *>(dd->sph);
+  const V3 w = xfApply(T, mk(sl.x, sl.y, sl.z));
+  CullSph o;
+  o.c[0] = w.x; o.c[1] = w.y; o.c[2] = w.z; o.r = sl.w;
+  o.obj = dd->obj; o.group = dd->group;
+  return o;
+}
+
 // -----------------------------------------------------------------------------------------------------------------
 // k_fk: RobotAndDOF::SetDOFValues (configuration_space.cpp:12-23) + link->GetTransform() for every link, plus what
 // UpdateBulletFromRave / updateAabbs do for the robot's links (bullet_collision_checker.cpp:648-653).
 // -----------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_fk(DevRobot rb, DevScene sc, DynMap dm, const double *__restrict__ dofs, int n_cfg, float d,
                                            double *__restrict__ linkQT, double *__restrict__ objQT, float *__restrict__ dynXf,
-                                           float *__restrict__ dynAabb, double *__restrict__ linkZ = nullptr) {
+                                           float *__restrict__ dynAabb, double *__restrict__ linkZ = nullptr, CullSph *__restrict__ dynSph = nullptr) {
   extern __shared__ double s_motion[];  // [n_links][7]
   const int s = blockIdx.x;
   if (s >= n_cfg) return;
@@ -251,6 +262,7 @@ __global__ void __launch_bounds__(64) k_fk(DevRobot rb, DevScene sc, DynMap dm, 
                            mk(sc.shape_lmax[3 * sh], sc.shape_lmax[3 * sh + 1], sc.shape_lmax[3 * sh + 2]), Tc, d);
         float *ob = dynAabb + o * 6;
         ob[0] = b.lo.x; ob[1] = b.lo.y; ob[2] = b.lo.z; ob[3] = b.hi.x; ob[4] = b.hi.y; ob[5] = b.hi.z;
+        if (dynSph) dynSph[o] = movingSph(sc, c, Tc);
       }
     }
   }
@@ -259,7 +271,7 @@ __global__ void __launch_bounds__(64) k_fk(DevRobot rb, DevScene sc, DynMap dm, 
 // k_dyn_children ("poses" mode): object pose (7 doubles) -> fp32 transform exactly as toBt() does, child world
 // transform (orgTrans*childTrans for compounds, btCompoundCollisionAlgorithm.cpp:122-125) and the cull box.
 __global__ void k_dyn_children(DevScene sc, DynMap dm, const double *__restrict__ objQT, int n_sets, float d, float *__restrict__ dynXf,
-                               float *__restrict__ dynAabb) {
+                               float *__restrict__ dynAabb, CullSph *__restrict__ dynSph = nullptr) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)n_sets * dm.n_dyn_children;
   if (i >= total) return;
@@ -274,6 +286,7 @@ __global__ void k_dyn_children(DevScene sc, DynMap dm, const double *__restrict_
                      mk(sc.shape_lmax[3 * sh], sc.shape_lmax[3 * sh + 1], sc.shape_lmax[3 * sh + 2]), T, d);
   float *o = dynAabb + i * 6;
   o[0] = b.lo.x; o[1] = b.lo.y; o[2] = b.lo.z; o[3] = b.hi.x; o[4] = b.hi.y; o[5] = b.hi.z;
+  if (dynSph) dynSph[i] = movingSph(sc, c, T);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -370,11 +383,13 @@ __device__ __forceinline__ Xf childXf(const NarrowArgs &a, const float *dyn, int
 }
 // one side of a pair: shape into registers + its world pose(s)
 template <int G>
-__device__ __forceinline__ void loadSide(const NarrowArgs &a, int child, const ChildDesc &cd, int set0, int set1, bool cast, Cvx<G> &c, Xf &t0) {
+// (slot: the child's slot in the pose tables when the caller knows it, -1 if it never moves, -2 = look it up)
+__device__ __forceinline__ void loadSide(const NarrowArgs &a, int child, const ChildDesc &cd, int set0, int set1, bool cast, Cvx<G> &c, Xf &t0, int slot = -2) {
   cvxLoad<G>(c, cd.kind, mk(cd.dims[0], cd.dims[1], cd.dims[2]), a.sc.vx, a.sc.vy, a.sc.vz, a.sc.v4, cd.voff, cd.vcnt);
-  t0 = childXf(a, a.dynXf0, set0, child);
+  if (slot == -2) slot = a.dm.child_dyn[child];
+  t0 = slot >= 0 ? ldXf(a.dynXf0 + ((size_t)set0 * a.dm.n_dyn_children + slot) * 12) : ldXf(a.sc.stat_xf + 12 * child);
   if (cast) {
-    Xf t1 = childXf(a, a.dynXf1, set1, child);
+    Xf t1 = slot >= 0 ? ldXf(a.dynXf1 + ((size_t)set1 * a.dm.n_dyn_children + slot) * 12) : ldXf(a.sc.stat_xf + 12 * child);
     c.cast = 1;
     c.t01 = xfInverseTimes(t0, t1);  // CastHullShape(convex, tf0.inverseTimes(tf1)), bullet_collision_checker.cpp:977
   }
@@ -405,6 +420,7 @@ struct CullArgs {
   const int *qchildren;
   int nQ;
   const float *dynAabb0, *dynAabb1;
+  const CullSph *dynSph0;   // [n_sets][moving children]: bounding spheres at the (first) pose of each set
   int pretest;
   int dbg;   // timing experiments only (TOHC_BP_DBG): 1 = count the box-test survivors and drop them, 2 = stage 1 only, drop the rest
 };
@@ -437,15 +453,11 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
   // with the scan's instead of starting a chain of their own at the first drain
   Cvx<1> cq;
   Xf tq;
-  if (ca.pretest) loadSide<1>(a, q, sc.child_desc[q], set0, set1, CAST, cq, tq);
+  if (ca.pretest) loadSide<1>(a, q, sc.child_desc[q], set0, set1, CAST, cq, tq, qs);
   // first block of the moving children's boxes, likewise ahead of the scan of the static table
-  int dyn0 = 0;
   Aabb bd0;
   bd0.lo = mk(1.f, 1.f, 1.f); bd0.hi = mk(-1.f, -1.f, -1.f);
-  if (lane < dm.n_dyn_children && ca.dbg != 4) {
-    dyn0 = dm.dyn_children[lane];
-    bd0 = ldAabb(ca.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + lane) * 6);
-  }
+  if (lane < dm.n_dyn_children && ca.dbg != 4) bd0 = ldAabb(ca.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + lane) * 6);
 
   // The queued box-test survivors, one lane per pair: object-level filters (here and not in the scan loop: they are
   // three dependent loads, which per overlapping cluster made the scan a chain of ~100 L2 round trips per wavefront),
@@ -455,7 +467,7 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
     for (unsigned int k0 = 0; k0 < nq; k0 += TOHC_BP_THREADS) {
       const unsigned int k = k0 + lane;
       bool keep = k < nq;
-      int x = 0;
+      int x = 0, xSlot = 0;   // the other child's number; for one that moves also its slot in the pose tables
       bool xDyn = false;
       V3 c = mk(0.f, 0.f, 0.f);   // the other child's bounding sphere, world coordinates
       float rad = 0.f;
@@ -463,19 +475,15 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
         const int ent = s_q[k];
         x = ent & ~TOHC_BP_DYN;
         xDyn = (ent & TOHC_BP_DYN) != 0;
-        int X, gx;
-        if (ent & TOHC_BP_DYN) {   // a moving child: sphere through its pose of this set
-          const ChildDesc *dd = sc.child_desc + x;
-          X = dd->obj; gx = dd->group;
-          const F4 sl = *reinterpret_cast<const F4 *>(dd->sph);
-          c = xfApply(childXf(a, a.dynXf0, set0, x), mk(sl.x, sl.y, sl.z));
-          rad = sl.w;
-        } else {                   // never moves: one 32-byte record, no pose, no descriptor
-          const CullSph sx = sc.stat_sph[x];
-          X = sx.obj; gx = sx.group;
-          c = mk(sx.c[0], sx.c[1], sx.c[2]);
-          rad = sx.r;
-        }
+        xSlot = x;
+        // one 32-byte record either way: the child's bounding sphere in the world + its object / group words (a child that
+        // never moves: made on the host with the static poses; one that moves: by k_fk / k_dyn_children for this set --
+        // queue entries of moving children carry their slot, not their number)
+        const CullSph sx = xDyn ? ca.dynSph0[(size_t)set0 * dm.n_dyn_children + x] : sc.stat_sph[x];
+        if (xDyn) x = dm.dyn_children[x];
+        const int X = sx.obj, gx = sx.group;
+        c = mk(sx.c[0], sx.c[1], sx.c[2]);
+        rad = sx.r;
         // discrete: contactTest skips the query object itself (btCollisionWorld.cpp:1132-1133).  Cast: the swept shape is a
         // temporary object that is not in the world, so nothing is skipped -- a query link whose own object passes the
         // KinBodyFilter mask (a grabbed body's link) meets its resting self, as in the reference (bcc:983, 886-892)
@@ -501,7 +509,7 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
           } else if (TOHC_BP_EXACT) {
             const ChildDesc dx = sc.child_desc[x];
             // (a child that never moves: its pose straight from the static table, no look-up of its slot first)
-            const Xf tx = xDyn ? childXf(a, a.dynXf0, set0, x) : ldXf(sc.stat_xf + 12 * x);
+            const Xf tx = xDyn ? ldXf(a.dynXf0 + ((size_t)set0 * dm.n_dyn_children + xSlot) * 12) : ldXf(sc.stat_xf + 12 * x);
             Cvx<1> cx;
             cvxLoad<1>(cx, dx.kind, mk(dx.dims[0], dx.dims[1], dx.dims[2]), sc.vx, sc.vy, sc.vz, sc.v4, dx.voff, dx.vcnt);
             const V3 qB = xfApply(tx, supNV<1>(cx, mulVM(dir, tx.b)));
@@ -587,16 +595,12 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
     }
   }
   // moving children (the first block was loaded at the top)
-  if (ca.dbg != 4 && dm.n_dyn_children > 0) push(lane < dm.n_dyn_children && aabbOverlap(bq, bd0), dyn0 | TOHC_BP_DYN);
+  if (ca.dbg != 4 && dm.n_dyn_children > 0) push(lane < dm.n_dyn_children && aabbOverlap(bq, bd0), lane | TOHC_BP_DYN);
   for (int base = TOHC_BP_THREADS; base < (ca.dbg == 4 ? 0 : dm.n_dyn_children); base += TOHC_BP_THREADS) {
     const int i = base + lane;
     bool hit = false;
-    int chx = 0;
-    if (i < dm.n_dyn_children) {
-      chx = dm.dyn_children[i];
-      hit = aabbOverlap(bq, ldAabb(ca.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + i) * 6));
-    }
-    push(hit, chx | TOHC_BP_DYN);
+    if (i < dm.n_dyn_children) hit = aabbOverlap(bq, ldAabb(ca.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + i) * 6));
+    push(hit, i | TOHC_BP_DYN);
   }
   if (nq > 0) drain();
   if (lane == 0 && ncand > 0) atomicAdd(&a.cnt->sh[shard].n_cand, ncand);
