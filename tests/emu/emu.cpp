@@ -64,6 +64,13 @@ bool pairEval(World *w, const Cvx<1> &A, const Xf &tA, const Cvx<1> &B, const Xf
   }
   g_pre[pre]++;
   gjkMain<1>(A, B, tA, tB, md, st);
+  if (const char *lg = getenv("EMU_GJK_LOG")) {   // diagnostics: what a GJK run's length depends on (pairs the pre-test passes on)
+    static FILE *f = fopen(lg, "w");
+    V3 dir = tA.o - tB.o, ww;
+    float delta = 0;
+    if (len2(dir) > 1e-12f) { dir = vdiv(dir, len(dir)); sepAxisBeyond<1>(A, B, tA, tB, dir, 0.f, ww); delta = dot(dir, ww); }
+    if (!pre) fprintf(f, "%d %g %d %d %d\n", st.iters, (double)delta, A.n, B.n, (int)st.needEpa), fflush(f);
+  }
   g_iter_hist[st.iters < 63 ? st.iters : 63]++;
   g_epa_hist[st.needEpa ? 1 : 0]++;
   if (st.needEpa) {
