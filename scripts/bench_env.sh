@@ -1,9 +1,10 @@
 #!/bin/bash
-# bash scripts/bench_env.sh TAG "ENV=1 ENV2=2" ...  -> one short hot-path bench per environment set (GPU box)
+# bash scripts/bench_env.sh TAG "ENV=1 ENV2=2" ...  -> one short hot-path bench per environment set (GPU box);
+# BENCH_ARGS adds arguments to bench.py (e.g. BENCH_ARGS="--config multistart")
 TAG=$1; shift
 for envs in "$@"; do
   name=$(echo "$envs" | tr ' =/' '___' | tail -c 60)
-  env $envs timeout -k 10 200 python3 bench.py --no-cpu-baseline --hot-path-only --min-seconds 0.5 > gpurun_out/${TAG}_${name}.json 2> gpurun_out/${TAG}_${name}.err || echo "FAILED $envs"
+  env $envs timeout -k 10 200 python3 bench.py --no-cpu-baseline --hot-path-only --min-seconds 0.5 $BENCH_ARGS > gpurun_out/${TAG}_${name}.json 2> gpurun_out/${TAG}_${name}.err || echo "FAILED $envs"
   python3 - "$envs" gpurun_out/${TAG}_${name}.json <<'PY'
 import json, sys
 j = json.loads(open(sys.argv[2]).read())
