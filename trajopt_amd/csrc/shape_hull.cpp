@@ -94,8 +94,8 @@ class HullBuilder {
   }
   static bool hasVert(const HullTri &t, int v) { return t.v[0] == v || t.v[1] == v || t.v[2] == v; }
   // the neighbour slot of triangle `id` across its edge a-b (either direction)
+  int none = -1;               // where neib() points when there is no such edge (broken is set)
   int &neib(int id, int a, int b) {
-    static int none;
     if (id < 0 || id >= (int)tris.size() || !tris[id].alive) { broken = true; none = -1; return none; }
     HullTri &t = tris[id];
     for (int i = 0; i < 3; ++i) {
