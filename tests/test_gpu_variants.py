@@ -113,6 +113,25 @@ def test_engine_variants_compute_the_same_slab(built):
     w.close()
 
 
+def test_unit_broadphase_equals_per_query_broadphase(built):
+    """A small world (arm over a table and a box): by default ONE wavefront per unit does all its box tests
+    (k_broadphase_unit); TOHC_UNIT_BP=0 sends them through k_broadphase's wavefront per (unit, query child).  Same slab,
+    same pair-evaluation count."""
+    s = M.Scene()
+    rb = synth.pr2_like(s, seed=0, active="rightarm")
+    ids, boxT = synth.add_boxes(s, [synth.TABLE_BOX, ((.2, .3, .4), synth.T7((0.6, -0.6, 0.4), (0, 0, 1), 0.5))])
+    s.finalize(); rb.finalize()
+    static_T = synth.static_poses(s, ids, boxT)
+    Bp, Tt = 16, 10
+    rng = np.random.default_rng(21)
+    dofs = np.stack([synth.straight_line(rb.q_robot[1:8] + rng.uniform(-0.5, 0.5, 7), rb.q_robot[1:8] + rng.uniform(-0.9, 0.9, 7), Tt) for _ in range(Bp)])
+    ref_rec, ref_g, ref_c, allowed = _run({}, s, rb, static_T, dofs, Bp, Tt)
+    rec, g, c, _ = _run({"TOHC_UNIT_BP": "0"}, s, rb, static_T, dofs, Bp, Tt, allowed)
+    assert len(rec) == len(ref_rec) > 100
+    assert np.array_equal(rec, ref_rec) and np.array_equal(g, ref_g)
+    assert c["pair_evals"] == ref_c["pair_evals"] and c["gjk_evals"] == ref_c["gjk_evals"]
+
+
 def test_mimic_joint_falls_back_to_column_walk(built):
     """Two revolute joints of one chain driven by the same robot DOF (mult 1 and -0.5): their Jacobian columns add
     before the product with the normal, which only the lane-per-column epilogue does (DevRobot.fast_jac = 0)."""

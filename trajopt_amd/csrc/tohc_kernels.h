@@ -422,6 +422,7 @@ struct CullArgs {
   const float *dynAabb0, *dynAabb1;
   const CullSph *dynSph0;   // [n_sets][moving children]: bounding spheres at the (first) pose of each set
   int pretest;
+  int dyn_elsewhere;   // k_broadphase: the moving children are k_broadphase_unit's; k_broadphase_unit: 1 = it also takes the static ones
   int dbg;   // timing experiments only (TOHC_BP_DBG): 1 = count the box-test survivors and drop them, 2 = stage 1 only, drop the rest
 };
 template <bool CAST>
@@ -457,7 +458,7 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
   // first block of the moving children's boxes, likewise ahead of the scan of the static table
   Aabb bd0;
   bd0.lo = mk(1.f, 1.f, 1.f); bd0.hi = mk(-1.f, -1.f, -1.f);
-  if (lane < dm.n_dyn_children && ca.dbg != 4) bd0 = ldAabb(ca.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + lane) * 6);
+  if (lane < dm.n_dyn_children && ca.dbg != 4 && !ca.dyn_elsewhere) bd0 = ldAabb(ca.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + lane) * 6);
 
   // The queued box-test survivors, one lane per pair: object-level filters (here and not in the scan loop: they are
   // three dependent loads, which per overlapping cluster made the scan a chain of ~100 L2 round trips per wavefront),
@@ -595,12 +596,148 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
     }
   }
   // moving children (the first block was loaded at the top)
-  if (ca.dbg != 4 && dm.n_dyn_children > 0) push(lane < dm.n_dyn_children && aabbOverlap(bq, bd0), lane | TOHC_BP_DYN);
-  for (int base = TOHC_BP_THREADS; base < (ca.dbg == 4 ? 0 : dm.n_dyn_children); base += TOHC_BP_THREADS) {
+  if (ca.dbg != 4 && !ca.dyn_elsewhere && dm.n_dyn_children > 0) push(lane < dm.n_dyn_children && aabbOverlap(bq, bd0), lane | TOHC_BP_DYN);
+  for (int base = TOHC_BP_THREADS; base < (ca.dbg == 4 || ca.dyn_elsewhere ? 0 : dm.n_dyn_children); base += TOHC_BP_THREADS) {
     const int i = base + lane;
     bool hit = false;
     if (i < dm.n_dyn_children) hit = aabbOverlap(bq, ldAabb(ca.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + i) * 6));
     push(hit, i | TOHC_BP_DYN);
+  }
+  if (nq > 0) drain();
+  if (lane == 0 && ncand > 0) atomicAdd(&a.cnt->sh[shard].n_cand, ncand);
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// k_broadphase_unit: ONE WAVEFRONT per unit for everything a short list of boxes has to offer -- the moving children
+// (a robot's own links: 45 boxes on config 4, where a wavefront per (unit, query child) spent a quarter of its time on
+// one under-filled round of them and its set-up), and in a small world (a table, a kitchen: the multi-start
+// configuration) the static children as well, in which case k_broadphase is not launched at all.  The wavefront walks
+// the unit's query children; every round tests the query's box against 64 of the list's; the survivors of ALL the
+// unit's queries share one LDS queue, so the drains run on full wavefronts.  A queue entry names its query, and the
+// pre-test loads the query side per lane.  Filters, pre-test and counting are k_broadphase's.
+// -----------------------------------------------------------------------------------------------------------------
+#define TOHC_BPU_QCAP 512
+#define TOHC_BPU_DYN (1u << 22)      // queue entries: query number << 23 | this bit for a moving child (then its slot) | child number
+#define TOHC_BPU_MAX_Q 512
+#define TOHC_BPU_MAX_CHILD (1u << 22)
+template <bool CAST>
+__global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase_unit(CullArgs ca) {
+  const NarrowArgs &a = ca.a;
+  const DevScene &sc = a.sc;
+  const DynMap &dm = a.dm;
+  const CallParams &cp = a.cp;
+  __shared__ unsigned int s_q[TOHC_BPU_QCAP];
+  const int lane = threadIdx.x;
+  const int cs = cp.unit_base + blockIdx.x;
+  const int shard = blockIdx.x % TOHC_NSHARD;
+  int set0, set1;
+  castSets(cp, cs, set0, set1);
+  const float lim = cp.d * 1.01f + 1.0e-4f;
+  unsigned int nq = 0, ncand = 0;   // wave-uniform
+  const int nStat = (ca.dyn_elsewhere && dm.n_stat > 0) ? dm.n_stat_pad : 0;   // ("poses" mode: no static table at all)
+  const int nO = nStat + dm.n_dyn_children;
+
+  auto drain = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the queue is this wavefront's own: its LDS operations are in order
+    for (unsigned int k0 = 0; k0 < nq; k0 += TOHC_BP_THREADS) {
+      const unsigned int k = k0 + lane;
+      bool keep = k < nq;
+      int x = 0, xSlot = 0, q = 0, qs = -1;
+      bool xDyn = false;
+      V3 c = mk(0.f, 0.f, 0.f);
+      float rad = 0.f;
+      if (keep) {
+        const unsigned int ent = s_q[k];
+        const int4 qinfo = reinterpret_cast<const int4 *>(ca.qchildren)[ent >> 23];   // (child, object, moving slot or -1, 0)
+        q = qinfo.x; qs = qinfo.z;
+        const int Q = qinfo.y;
+        x = (int)(ent & (TOHC_BPU_DYN - 1u));
+        xDyn = (ent & TOHC_BPU_DYN) != 0;
+        xSlot = x;
+        const CullSph sx = xDyn ? ca.dynSph0[(size_t)set0 * dm.n_dyn_children + x] : sc.stat_sph[x];
+        if (xDyn) x = dm.dyn_children[x];
+        const int X = sx.obj, gx = sx.group;
+        c = mk(sx.c[0], sx.c[1], sx.c[2]);
+        rad = sx.r;
+        // (k_broadphase's filters: contactTest skips the query object itself, the swept shape of a cast meets everything)
+        keep = (CAST || X != Q) && (CAST ? (gx & TOHC_GROUP_KINBODY) != 0 : (gx & (short)cp.filter_mask) != 0) &&
+               sc.allowed[(size_t)Q * sc.n_objects + X] != 0 && (!cp.ordered_pairs || X > Q);
+      }
+      ncand += (unsigned int)__popcll(__ballot(keep));
+      if (ca.dbg == 1) keep = false;
+      if (keep && ca.pretest) {
+        Cvx<1> cq;
+        Xf tq;
+        loadSide<1>(a, q, sc.child_desc[q], set0, set1, CAST, cq, tq, qs);
+        const V3 dir = tq.o - c;
+        const float dl2 = len2(dir);
+        if (dl2 > 1.0e-12f) {
+          const float dl = sqrtf(dl2);
+          const V3 pA = xfApply(tq, supNV<1>(cq, mulVM(-dir, tq.b)));
+          const float mq = cvxMargin<1>(cq);
+          const float deltaS = dot(dir, pA - c) - (rad + mq) * dl;
+          if ((deltaS > 0.0f && deltaS > lim * dl) || ca.dbg == 2) {
+            keep = false;
+          } else if (TOHC_BP_EXACT) {
+            const ChildDesc dx = sc.child_desc[x];
+            const Xf tx = xDyn ? ldXf(a.dynXf0 + ((size_t)set0 * dm.n_dyn_children + xSlot) * 12) : ldXf(sc.stat_xf + 12 * x);
+            Cvx<1> cx;
+            cvxLoad<1>(cx, dx.kind, mk(dx.dims[0], dx.dims[1], dx.dims[2]), sc.vx, sc.vy, sc.vz, sc.v4, dx.voff, dx.vcnt);
+            const V3 qB = xfApply(tx, supNV<1>(cx, mulVM(dir, tx.b)));
+            const float delta = dot(dir, pA - qB);
+            const float limm = lim + (mq + cvxMargin<1>(cx));
+            keep = !((delta > 0.0f) && (delta * delta > (limm * limm) * dl2));
+          }
+        }
+      }
+      const unsigned long long m = __ballot(keep);
+      const unsigned int cnt = (unsigned int)__popcll(m);
+      if (cnt > 0) {
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(&a.cnt->sh[shard].n_pairs, cnt);
+        base = __shfl(base, 0);
+        if (keep) {
+          const unsigned int pos = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+          if (pos < cp.seg_cap) {
+            PairRec p;
+            p.set = cs; p.q = q; p.x = x; p.pad = 0;
+            a.pairs[(size_t)shard * cp.seg_cap + pos] = p;
+          } else {
+            a.cnt->overflow = 1;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    nq = 0;
+  };
+
+  for (int qi = 0; qi < ca.nQ; ++qi) {
+    const int4 qinfo = reinterpret_cast<const int4 *>(ca.qchildren)[qi];
+    const int q = qinfo.x, qs = qinfo.z;
+    Aabb bq = qs >= 0 ? ldAabb(ca.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + qs) * 6) : ldAabb(sc.stat_aabb + 6 * q);
+    if (CAST && qs >= 0) bq = aabbUnion(bq, ldAabb(ca.dynAabb1 + ((size_t)set1 * dm.n_dyn_children + qs) * 6));
+    for (int ob = 0; ob < nO; ob += TOHC_BP_THREADS) {
+      const int o = ob + lane;
+      bool hit = false;
+      unsigned int ent = (unsigned int)qi << 23;
+      if (o < nStat) {           // pad entries hold inverted boxes: they never overlap
+        const float *t = dm.stat_soa + o;
+        const int P = dm.n_stat_pad;
+        Aabb bx;
+        bx.lo = mk(t[0], t[P], t[2 * P]);
+        bx.hi = mk(t[3 * P], t[4 * P], t[5 * P]);
+        hit = aabbOverlap(bq, bx);
+        ent |= (unsigned int)dm.stat_children[o];
+      } else if (o < nO) {
+        hit = aabbOverlap(bq, ldAabb(ca.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + (o - nStat)) * 6));
+        ent |= TOHC_BPU_DYN | (unsigned int)(o - nStat);
+      }
+      const unsigned long long m = __ballot(hit);
+      if (hit) s_q[nq + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = ent;
+      nq += (unsigned int)__popcll(m);
+      if (nq > TOHC_BPU_QCAP - TOHC_BP_THREADS) drain();
+    }
   }
   if (nq > 0) drain();
   if (lane == 0 && ncand > 0) atomicAdd(&a.cnt->sh[shard].n_cand, ncand);
