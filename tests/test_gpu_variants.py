@@ -114,9 +114,9 @@ def test_engine_variants_compute_the_same_slab(built):
 
 
 def test_unit_broadphase_equals_per_query_broadphase(built):
-    """A small world (arm over a table and a box): by default ONE wavefront per unit does all its box tests
-    (k_broadphase_unit); TOHC_UNIT_BP=0 sends them through k_broadphase's wavefront per (unit, query child).  Same slab,
-    same pair-evaluation count."""
+    """A small world (arm over a table and a box): with enough units (default: 1024; here forced with TOHC_UNIT_BP=1) ONE
+    wavefront per unit does all its box tests (k_broadphase_unit); TOHC_UNIT_BP=0 sends them through k_broadphase's
+    wavefront per (unit, query child).  Same slab, same pair-evaluation count."""
     s = M.Scene()
     rb = synth.pr2_like(s, seed=0, active="rightarm")
     ids, boxT = synth.add_boxes(s, [synth.TABLE_BOX, ((.2, .3, .4), synth.T7((0.6, -0.6, 0.4), (0, 0, 1), 0.5))])
@@ -125,7 +125,7 @@ def test_unit_broadphase_equals_per_query_broadphase(built):
     Bp, Tt = 16, 10
     rng = np.random.default_rng(21)
     dofs = np.stack([synth.straight_line(rb.q_robot[1:8] + rng.uniform(-0.5, 0.5, 7), rb.q_robot[1:8] + rng.uniform(-0.9, 0.9, 7), Tt) for _ in range(Bp)])
-    ref_rec, ref_g, ref_c, allowed = _run({}, s, rb, static_T, dofs, Bp, Tt)
+    ref_rec, ref_g, ref_c, allowed = _run({"TOHC_UNIT_BP": "1"}, s, rb, static_T, dofs, Bp, Tt)
     rec, g, c, _ = _run({"TOHC_UNIT_BP": "0"}, s, rb, static_T, dofs, Bp, Tt, allowed)
     assert len(rec) == len(ref_rec) > 100
     assert np.array_equal(rec, ref_rec) and np.array_equal(g, ref_g)

@@ -207,7 +207,8 @@ struct tohc_engine {
   int gjk_group = 1;  // lanes per pair in k_gjk: 1 (default), 16 or 64 (TOHC_GJK_GROUP)
   int pen_group = 1;   // lanes per pair in k_pen: 1, or 4 (hull vertices in registers; TOHC_PEN_GROUP=4: measured no faster, GJK2's LDS bookkeeping dominates)
   int epa_block = 64;  // threads per k_epa block (TOHC_EPA_BLOCK = 16 or 64)
-  int unit_broadphase = 1;   // TOHC_UNIT_BP=0: every box test in k_broadphase (one wavefront per (unit, query child)), as in round 1
+  int unit_broadphase = 1024;   // k_broadphase_unit from this many units on (one wavefront per unit: fewer units leave the chip empty and
+                                // a wavefront per (unit, query child) answers sooner); TOHC_UNIT_BP=n sets it, 0 = never
   unsigned int epa_small_v = TOHC_EPA_SMALL_V, epa_small_f = TOHC_EPA_SMALL_F;   // TOHC_EPA_SMALL=v,f shrinks k_tail_epa's first-attempt pools (tests of the repeat path)
   int pretest = 1;   // TOHC_PRETEST=0 turns the separating-axis pre-test off (A/B measurements)
   tohc_engine() { memset(&counters, 0, sizeof counters); }
@@ -334,7 +335,7 @@ int tohc_create(tohc_engine **out, int device) {
   }
   if (const char *mt = getenv("TOHC_MERGE_TAIL")) e->max_open = atoi(mt) != 0 ? TOHC_MAX_HEADS : 1;
   if (const char *eb = getenv("TOHC_EPA_BLOCK")) e->epa_block = atoi(eb) == 16 ? 16 : 64;
-  if (const char *ub = getenv("TOHC_UNIT_BP")) e->unit_broadphase = atoi(ub) != 0;
+  if (const char *ub = getenv("TOHC_UNIT_BP")) e->unit_broadphase = std::max(atoi(ub), 0);
   if (const char *es = getenv("TOHC_EPA_SMALL")) {
     unsigned int v = 0, f = 0;
     if (sscanf(es, "%u,%u", &v, &f) == 2 && v >= 1 && f >= 4) { e->epa_small_v = std::min(v, (unsigned int)TOHC_EPA_SMALL_V); e->epa_small_f = std::min(f, (unsigned int)TOHC_EPA_SMALL_F); }
@@ -1087,7 +1088,7 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
     // all and k_broadphase is not launched; else a wavefront per (unit, query child) walks the cluster table and the
     // moving children.  (Giving only the moving children of a large world to the unit kernel was measured too: no gain,
     // 0.72 vs 0.69 ms per launch on config 4.)
-    const bool unitOk = e->unit_broadphase && nQ <= TOHC_BPU_MAX_Q && (unsigned)e->n_children < TOHC_BPU_MAX_CHILD && ca.dbg == 0;
+    const bool unitOk = e->unit_broadphase > 0 && cp.n_cast_sets >= e->unit_broadphase && nQ <= TOHC_BPU_MAX_Q && (unsigned)e->n_children < TOHC_BPU_MAX_CHILD && ca.dbg == 0;
     const bool unitAll = unitOk && (size_t)nQ * ((dm.n_stat > 0 ? dm.n_stat_pad : 0) + dm.n_dyn_children) <= 64 * 96;
     const bool unitDyn = false;
     if (unitAll) {
