@@ -127,6 +127,7 @@ struct tohc_engine {
     DBuf<PairRec> pairs;
     DBuf<EpaRec> epaq;
     DBuf<PenRec> penq;
+    DBuf<unsigned int> distq;
     DBuf<HitRec> hits;
   };
   Lane lane[4];
@@ -933,6 +934,9 @@ static int64_t countAabbTests(const tohc_engine *e, const std::vector<int> &qchi
 #ifndef TOHC_GJK_GRID
 #define TOHC_GJK_GRID 16384   // lane-per-pair blocks of one wavefront: many small blocks, so the hardware dispatcher balances the uneven runs (4096: 0.51 ms per launch, 16384: 0.37)
 #endif
+#ifndef TOHC_DIST_BLOCKS
+#define TOHC_DIST_BLOCKS 256   // blocks of k_tail_epa that run the Distance fall-back
+#endif
 #ifndef TOHC_EPA_GRID
 #define TOHC_EPA_GRID 2048
 #endif
@@ -979,15 +983,20 @@ static int launchTail(tohc_engine *e) {
       if (e->pen_group == 4) hipLaunchKernelGGL((k_tail_pen<4, 1, 2>), dim3(gridN), dim3(64), 0, ts, ta);
       else if (cast) hipLaunchKernelGGL((k_tail_pen<1, 1, 1>), dim3(gridN), dim3(64), 0, ts, ta);
       else hipLaunchKernelGGL((k_tail_pen<1, 1, 0>), dim3(gridN), dim3(64), 0, ts, ta);
-      if (e->group == 64) hipLaunchKernelGGL((k_tail_epa<64, 64, 1>), dim3(gridN), dim3(64), 0, ts, ta);
-      else if (e->epa_block == 16) hipLaunchKernelGGL((k_tail_epa<16, 16, 1>), dim3(gridN * 4), dim3(16), 0, ts, ta);  // one group per wavefront
-      else hipLaunchKernelGGL((k_tail_epa<TOHC_EPA_G, 64, 1>), dim3(TOHC_EPA_GRID), dim3(64), 0, ts, ta);
+      // (+ the blocks of the Distance fall-back at the head of the grid, one lane per pair)
+      ta.n_dist_blocks = e->pen_group == 1 ? (e->epa_block == 16 ? 4 * TOHC_DIST_BLOCKS : TOHC_DIST_BLOCKS) : 0;
+      const unsigned int nd = ta.n_dist_blocks;
+      if (e->group == 64) hipLaunchKernelGGL((k_tail_epa<64, 64, 1>), dim3(gridN + nd), dim3(64), 0, ts, ta);
+      else if (e->epa_block == 16) hipLaunchKernelGGL((k_tail_epa<16, 16, 1>), dim3(gridN * 4 + nd), dim3(16), 0, ts, ta);  // one group per wavefront
+      else hipLaunchKernelGGL((k_tail_epa<TOHC_EPA_G, 64, 1>), dim3(TOHC_EPA_GRID + nd), dim3(64), 0, ts, ta);
     } else {   // nh == TOHC_MAX_HEADS == 2
       if (e->pen_group == 4) hipLaunchKernelGGL((k_tail_pen<4, 2, 2>), dim3(gridN * 2), dim3(64), 0, ts, ta);
       else hipLaunchKernelGGL((k_tail_pen<1, 2, 2>), dim3(gridN * 2), dim3(64), 0, ts, ta);
-      if (e->group == 64) hipLaunchKernelGGL((k_tail_epa<64, 64, 2>), dim3(gridN * 2), dim3(64), 0, ts, ta);
-      else if (e->epa_block == 16) hipLaunchKernelGGL((k_tail_epa<16, 16, 2>), dim3(gridN * 4 * 2), dim3(16), 0, ts, ta);
-      else hipLaunchKernelGGL((k_tail_epa<TOHC_EPA_G, 64, 2>), dim3(TOHC_EPA_GRID * 2), dim3(64), 0, ts, ta);
+      ta.n_dist_blocks = e->pen_group == 1 ? (e->epa_block == 16 ? 4 * TOHC_DIST_BLOCKS : TOHC_DIST_BLOCKS) : 0;
+      const unsigned int nd = ta.n_dist_blocks;
+      if (e->group == 64) hipLaunchKernelGGL((k_tail_epa<64, 64, 2>), dim3(gridN * 2 + nd), dim3(64), 0, ts, ta);
+      else if (e->epa_block == 16) hipLaunchKernelGGL((k_tail_epa<16, 16, 2>), dim3(gridN * 4 * 2 + nd), dim3(16), 0, ts, ta);
+      else hipLaunchKernelGGL((k_tail_epa<TOHC_EPA_G, 64, 2>), dim3(TOHC_EPA_GRID * 2 + nd), dim3(64), 0, ts, ta);
     }
   }
   // A hinge assembly may still be reading the previous slab (tohc_fetch_hinges_begin): the broadphase, GJK and the
@@ -1056,6 +1065,7 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
   const size_t qcap = (size_t)cp.seg_cap * TOHC_NSHARD;
   HIPCHK(ln.pairs.reserve(qcap)); HIPCHK(ln.epaq.reserve(qcap)); HIPCHK(ln.hits.reserve(qcap));
   HIPCHK(ln.penq.reserve((size_t)(cp.seg_cap / TOHC_PEN_DIV) * TOHC_NSHARD));
+  HIPCHK(ln.distq.reserve(qcap));
 #if defined(TOHC_EPA_PROF)
   if (!e->d_dbg.p) { HIPCHK(e->d_dbg.reserve(160)); HIPCHK(hipMemset(e->d_dbg.p, 0, 160 * sizeof(unsigned long long))); }
 #endif
@@ -1072,7 +1082,7 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
   a.linkQT = robotMode ? e->d_linkQT.p : nullptr;
   a.linkZ = robotMode ? e->d_linkZ.p : nullptr;
   a.dofs = robotMode ? e->d_dofs.p : nullptr;
-  a.pairs = ln.pairs.p; a.epaq = ln.epaq.p; a.penq = ln.penq.p; a.hits = ln.hits.p; a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p; a.rec_base = e->d_rec_base.p + slot;
+  a.pairs = ln.pairs.p; a.epaq = ln.epaq.p; a.penq = ln.penq.p; a.distq = ln.distq.p; a.hits = ln.hits.p; a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p; a.rec_base = e->d_rec_base.p + slot;
   a.records = e->d_records.p; a.grads = e->d_grads.p; a.dbg = e->d_dbg.p;
   if (!oh.empty) {
     const size_t blocks = (size_t)cp.n_cast_sets * nQ;

@@ -102,7 +102,8 @@ struct Counters {
   CounterShard sh[TOHC_NSHARD];
   unsigned int overflow;
   unsigned int epa_next;   // k_epa's work counter: wavefronts take the next BLOCK / G pairs when they are done with theirs
-  unsigned int pad[30];
+  unsigned int n_dist;     // pairs whose origin is outside (k_tail_pen) and that need the Distance fall-back (NarrowArgs.distq)
+  unsigned int pad[29];
 };
 #define TOHC_CNT_STRIDE (sizeof(CounterShard) / sizeof(unsigned int))
 
@@ -352,6 +353,7 @@ struct NarrowArgs {
   PairRec *pairs;
   EpaRec *epaq;
   PenRec *penq;
+  unsigned int *distq;    // positions in epaq of the pairs for the Distance fall-back (k_tail_pen -> the extra blocks of k_tail_epa)
   HitRec *hits;
   Counters *cnt;
   unsigned int *n_records;   // records the slab holds once every enqueue so far has finished -- advanced by k_range
@@ -1109,6 +1111,7 @@ __device__ __forceinline__ void loadQueued(const NarrowArgs &a, const EpaRec &e,
 #define TOHC_MAX_HEADS 2
 struct TailArgs {
   int n_heads;
+  unsigned int n_dist_blocks;  // k_tail_epa: its first n_dist_blocks blocks run the Distance fall-back (dispatched first: they start beside the first EPA runs), the rest EPA
   NarrowArgs h[TOHC_MAX_HEADS];
 };
 
@@ -1139,7 +1142,8 @@ __global__ void __launch_bounds__(64, TOHC_PEN_WAVES) k_tail_pen(TailArgs ta) {
   const unsigned int cap2 = a.cp.seg_cap / TOHC_PEN_DIV;
   unsigned int sups = 0;
   for (unsigned int i = gid; i < nepa; i += nlanes) {
-    const EpaRec e = a.epaq[qlocate(pre, a.cp.seg_cap, i)];
+    const unsigned int qpos = qlocate(pre, a.cp.seg_cap, i);
+    const EpaRec e = a.epaq[qpos];
     Cvx<G> A, B;
     Xf tA, tB, lA, lB;
     GjkState st;
@@ -1149,7 +1153,11 @@ __global__ void __launch_bounds__(64, TOHC_PEN_WAVES) k_tail_pen(TailArgs ta) {
     V3 tmpA = mk(0, 0, 0), tmpB = mk(0, 0, 0), sep = mk(0, 0, 0);
     bool isValid2 = false;
     Gjk2<G, G2Mem> g;
-    const bool toEpa = penStage1<G, G2Mem>(&mem[threadIdx.x / G], A, B, lA, lB, g, isValid2, sep, tmpA, tmpB);
+    // G == 1: only the first half of stage 1 here.  One pair in nine has the origin outside and needs Distance's GJK2 as
+    // well -- another run as long as the first, which EVERY wavefront of 64 pairs would sit through; those pairs are
+    // noted (distq) and finished by a few lane-per-pair blocks at the end of k_tail_epa's grid, beside the EPA runs.
+    const bool toEpa = G == 1 ? penInside<G, G2Mem>(&mem[threadIdx.x / G], A, B, lA, lB, g)
+                              : penStage1<G, G2Mem>(&mem[threadIdx.x / G], A, B, lA, lB, g, isValid2, sep, tmpA, tmpB);
     const int shard = blockIdx.x % TOHC_NSHARD;
     unsigned int slot = 0;
     bool writeP = toEpa;
@@ -1165,9 +1173,17 @@ __global__ void __launch_bounds__(64, TOHC_PEN_WAVES) k_tail_pen(TailArgs ta) {
         a.cnt->overflow = 1;
       }
     }
-    if (toEpa) st.isValid = false;   // no contact yet: k_tail_epa decides
-    else gjkFinishTail(isValid2, sep, tmpA, tmpB, st);
-    pushIfContact<G>(a, (unsigned int)e.pair, st, md2);
+    if (G == 1) {
+      const unsigned int ds = waveSlot(&a.cnt->n_dist, !toEpa);   // (one pair in nine, one atomic per wavefront: a single counter will do)
+      if (!toEpa) {
+        if (ds < a.cp.seg_cap * TOHC_NSHARD) a.distq[ds] = qpos;
+        else a.cnt->overflow = 1;
+      }
+    } else {
+      if (toEpa) st.isValid = false;   // no contact yet: k_tail_epa decides
+      else gjkFinishTail(isValid2, sep, tmpA, tmpB, st);
+      pushIfContact<G>(a, (unsigned int)e.pair, st, md2);
+    }
     if (Grp<G>::lane() == 0) sups += g.nsup;
   }
   waveAdd(&a.cnt->sh[blockIdx.x % TOHC_NSHARD].n_pen_sups, sups);
@@ -1182,8 +1198,41 @@ template <int G, int BLOCK, int NH>
 __global__ void __launch_bounds__(BLOCK, TOHC_EPA_WAVES) k_tail_epa(TailArgs ta) {
   static_assert(BLOCK <= 64, "the groups of a block take turns on one full pool: one wavefront per block");
   constexpr int groupsPerBlock = BLOCK / G;
-  constexpr size_t ldsBytes = sizeof(EpaMemS) * groupsPerBlock > sizeof(EpaMem) ? sizeof(EpaMemS) * groupsPerBlock : sizeof(EpaMem);
+  constexpr size_t ldsEpa = sizeof(EpaMemS) * groupsPerBlock > sizeof(EpaMem) ? sizeof(EpaMemS) * groupsPerBlock : sizeof(EpaMem);
+  constexpr size_t ldsBytes = ldsEpa > sizeof(G2Mem) * BLOCK ? ldsEpa : sizeof(G2Mem) * BLOCK;
   __shared__ __align__(16) unsigned char lds[ldsBytes];
+  if (blockIdx.x < ta.n_dist_blocks) {
+    // The Distance fall-back of the pairs k_tail_pen found the origin outside for (distq), one lane per pair, on the few
+    // blocks at the head of the grid: they run beside the EPA runs instead of inside every wavefront of k_tail_pen.
+    G2Mem *gm = reinterpret_cast<G2Mem *>(lds) + threadIdx.x;
+    const unsigned int b = blockIdx.x, nb = ta.n_dist_blocks;
+    unsigned int dsups = 0;
+    for (int hh = 0; hh < NH; ++hh) {
+      const NarrowArgs &a = ta.h[hh];
+      unsigned int n = a.cnt->n_dist;
+      if (n > a.cp.seg_cap * TOHC_NSHARD) n = a.cp.seg_cap * TOHC_NSHARD;
+      for (unsigned int i = b * BLOCK + threadIdx.x; i < n; i += nb * BLOCK) {
+        const EpaRec e = a.epaq[a.distq[i]];
+        Cvx<1> A, B;
+        Xf tA, tB, lA, lB;
+        GjkState st;
+        loadQueued<1>(a, e, a.cp.cast != 0, A, B, tA, tB, st);
+        const float md2 = pairMaxDist2<1>(A, B, a.cp.breaking);
+        penLocal(tA, tB, st.offset, lA, lB);
+        V3 tmpA = mk(0, 0, 0), tmpB = mk(0, 0, 0), sep = mk(0, 0, 0);
+        bool isValid2 = false;
+        Gjk2<1, G2Mem> g;
+        penDistance<1, G2Mem>(gm, A, B, lA, lB, g, isValid2, sep, tmpA, tmpB);
+        gjkFinishTail(isValid2, sep, tmpA, tmpB, st);
+        pushIfContact<1>(a, (unsigned int)e.pair, st, md2);
+        dsups += g.nsup;
+      }
+    }
+    unsigned int *dctr = &ta.h[0].cnt->sh[blockIdx.x % TOHC_NSHARD].n_pen_sups;
+    if (BLOCK >= 64) waveAdd(dctr, dsups);
+    else if (dsups) atomicAdd(dctr, dsups);
+    return;
+  }
   EpaMemS *ms = reinterpret_cast<EpaMemS *>(lds) + threadIdx.x / G;
   EpaMem *mb = reinterpret_cast<EpaMem *>(lds);
   unsigned int sups = 0, redone = 0;

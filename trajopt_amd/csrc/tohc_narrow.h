@@ -1372,16 +1372,25 @@ TOHC_DEV void g2Copy(MA *dst, const MB *src) {
     for (int q = 0; q < 2; ++q) { dst->sc[q][i] = src->sc[q][i]; dst->sp[q][i] = src->sp[q][i]; }
   }
 }
-// returns true when EPA is needed (g holds the state); else isValid2 / v / wA / wB are final
+// Stage 1 in its two halves (the device runs them in different kernels: the second one is needed by one pair in nine,
+// and a lane-per-pair wavefront that holds a single such pair sits through all of it):
+//   penInside():   the GJK2 of Penetration (with margins); true = the origin is inside, EPA is needed, g holds the state
+//   penDistance(): Distance's GJK2 (without margins) and its witness points; isValid2 / v / wA / wB are final
 template <int G, class MEM>
-TOHC_DEV bool penStage1(MEM *mem, const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &tB, Gjk2<G, MEM> &g, bool &isValid2, V3 &v, V3 &wA, V3 &wB) {
+TOHC_DEV bool penInside(MEM *mem, const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &tB, Gjk2<G, MEM> &g) {
+  V3 guess = tA.o - tB.o;
+  Mink<G> shape;
+  minkInit<G>(shape, &A, tA, &B, tB, true);
+  g.m = mem;
+  return g.evaluate(shape, -guess) == G2_INSIDE;
+}
+template <int G, class MEM>
+TOHC_DEV void penDistance(MEM *mem, const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &tB, Gjk2<G, MEM> &g, bool &isValid2, V3 &v, V3 &wA, V3 &wB) {
   V3 guess = tA.o - tB.o;
   Mink<G> shape;
   isValid2 = false;
-  minkInit<G>(shape, &A, tA, &B, tB, true);
-  g.m = mem;
-  if (g.evaluate(shape, -guess) == G2_INSIDE) return true;
   minkInit<G>(shape, &A, tA, &B, tB, false);
+  g.m = mem;
   int st = g.evaluate(shape, guess);
   if (st == G2_VALID) {
     V3 a = mk(0, 0, 0), b = mk(0, 0, 0);
@@ -1398,6 +1407,13 @@ TOHC_DEV bool penStage1(MEM *mem, const Cvx<G> &A, const Cvx<G> &B, const Xf &tA
     float dist = len(nrm);
     v = vdiv(nrm, dist > 0.0001f ? dist : 1);
   }
+}
+// both halves: returns true when EPA is needed (g holds the state); else isValid2 / v / wA / wB are final
+template <int G, class MEM>
+TOHC_DEV bool penStage1(MEM *mem, const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &tB, Gjk2<G, MEM> &g, bool &isValid2, V3 &v, V3 &wA, V3 &wB) {
+  isValid2 = false;
+  if (penInside<G, MEM>(mem, A, B, tA, tB, g)) return true;
+  penDistance<G, MEM>(mem, A, B, tA, tB, g, isValid2, v, wA, wB);
   return false;
 }
 // g: the state penStage1 left (restored into an EpaMem when the stages run in different kernels)
