@@ -20,7 +20,8 @@ pytestmark = pytest.mark.gpu
 
 VARIANTS = [{}, {"TOHC_PRETEST": "0"}, {"TOHC_STREAMS": "1"}, {"TOHC_CHUNKS": "2", "TOHC_STREAMS": "4"}, {"TOHC_HOST_SORT": "1"},
             {"TOHC_GJK_GROUP": "16"}, {"TOHC_EPA_BLOCK": "16"}, {"TOHC_GROUP": "64"}, {"TOHC_MERGE_TAIL": "1"},
-            {"TOHC_EPA_SMALL": "5,10"}]   # EPA's first-attempt pools so small that most runs are repeated on the full pools
+            {"TOHC_EPA_SMALL": "5,10"},   # EPA's first-attempt pools so small that most runs are repeated on the full pools
+            {"TOHC_DEFER_EXACT": "0"}]    # the exact stage of the pre-test inside k_broadphase instead of in k_exact
 
 
 def _world():
@@ -87,6 +88,8 @@ def test_engine_variants_compute_the_same_slab(built):
         assert c["pair_evals"] == ref_c["pair_evals"] and c["contacts"] == ref_c["contacts"], tag
         if env.get("TOHC_PRETEST") == "0":
             assert c["gjk_evals"] == c["pair_evals"]
+        if "TOHC_DEFER_EXACT" in env:   # the same test in either place: the same pairs reach k_gjk
+            assert c["gjk_evals"] == ref_c["gjk_evals"], tag
         if "TOHC_EPA_SMALL" in env:
             assert c["epa_redone"] > 0.05 * c["epa_evals"] > 0, (c["epa_redone"], c["epa_evals"])
     # and the slab is right: one problem against the oracle, pass by pass

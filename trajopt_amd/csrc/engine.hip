@@ -124,7 +124,7 @@ struct tohc_engine {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;       // recorded after the lane's latest k_finish
     hipEvent_t head_done = nullptr;  // recorded after the lane's latest k_gjk: the tail may start on that pass's queues
-    DBuf<PairRec> pairs;
+    DBuf<PairRec> pairs, cands;
     DBuf<EpaRec> epaq;
     DBuf<PenRec> penq;
     DBuf<unsigned int> distq;
@@ -211,6 +211,7 @@ struct tohc_engine {
   int unit_broadphase = 1024;   // k_broadphase_unit from this many units on (one wavefront per unit: fewer units leave the chip empty and
                                 // a wavefront per (unit, query child) answers sooner); TOHC_UNIT_BP=n sets it, 0 = never
   unsigned int epa_small_v = TOHC_EPA_SMALL_V, epa_small_f = TOHC_EPA_SMALL_F;   // TOHC_EPA_SMALL=v,f shrinks k_tail_epa's first-attempt pools (tests of the repeat path)
+  int defer_exact = 1;   // TOHC_DEFER_EXACT=0: the exact stage of the pre-test stays inside k_broadphase
   int pretest = 1;   // TOHC_PRETEST=0 turns the separating-axis pre-test off (A/B measurements)
   tohc_engine() { memset(&counters, 0, sizeof counters); }
 };
@@ -315,6 +316,7 @@ int tohc_create(tohc_engine **out, int device) {
   const char *g = getenv("TOHC_GROUP");
   if (g && atoi(g) == 64) e->group = 64;
   if (const char *pt = getenv("TOHC_PRETEST")) e->pretest = atoi(pt) != 0;
+  if (const char *pt = getenv("TOHC_DEFER_EXACT")) e->defer_exact = atoi(pt) != 0;
   if (const char *ns = getenv("TOHC_STREAMS")) e->n_lanes = std::min(std::max(atoi(ns), 1), 4);
   if (const char *nc = getenv("TOHC_CHUNKS")) e->chunks = std::min(std::max(atoi(nc), 1), 4);
   if (hipEventCreateWithFlags(&e->ev_fk, hipEventDisableTiming) != hipSuccess) { tohc_destroy(e); return TOHC_E_HIP; }
@@ -858,7 +860,7 @@ static int syncEngineImpl(tohc_engine *e) {
     overflow |= k.overflow != 0;
     for (int sh = 0; sh < TOHC_NSHARD; ++sh) {
       const CounterShard &cs = k.sh[sh];
-      overflow |= cs.n_pairs > segCap || cs.n_epa > segCap || cs.n_hits > segCap || cs.n_pen > segCap / TOHC_PEN_DIV;
+      overflow |= cs.n_pairs > segCap || cs.n_exact > segCap || cs.n_epa > segCap || cs.n_hits > segCap || cs.n_pen > segCap / TOHC_PEN_DIV;
       np += cs.n_cand; ng += cs.n_pairs; ne += cs.n_epa;
       gi += cs.n_gjk_steps; ps += cs.n_pen_sups; es += cs.n_epa_sups; er += cs.n_epa_redone;
     }
@@ -1066,6 +1068,7 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
   HIPCHK(ln.pairs.reserve(qcap)); HIPCHK(ln.epaq.reserve(qcap)); HIPCHK(ln.hits.reserve(qcap));
   HIPCHK(ln.penq.reserve((size_t)(cp.seg_cap / TOHC_PEN_DIV) * TOHC_NSHARD));
   HIPCHK(ln.distq.reserve(qcap));
+  if (e->defer_exact) HIPCHK(ln.cands.reserve(qcap));
 #if defined(TOHC_EPA_PROF)
   if (!e->d_dbg.p) { HIPCHK(e->d_dbg.reserve(160)); HIPCHK(hipMemset(e->d_dbg.p, 0, 160 * sizeof(unsigned long long))); }
 #endif
@@ -1082,7 +1085,7 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
   a.linkQT = robotMode ? e->d_linkQT.p : nullptr;
   a.linkZ = robotMode ? e->d_linkZ.p : nullptr;
   a.dofs = robotMode ? e->d_dofs.p : nullptr;
-  a.pairs = ln.pairs.p; a.epaq = ln.epaq.p; a.penq = ln.penq.p; a.distq = ln.distq.p; a.hits = ln.hits.p; a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p; a.rec_base = e->d_rec_base.p + slot;
+  a.pairs = ln.pairs.p; a.cands = ln.cands.p; a.epaq = ln.epaq.p; a.penq = ln.penq.p; a.distq = ln.distq.p; a.hits = ln.hits.p; a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p; a.rec_base = e->d_rec_base.p + slot;
   a.records = e->d_records.p; a.grads = e->d_grads.p; a.dbg = e->d_dbg.p;
   if (!oh.empty) {
     const size_t blocks = (size_t)cp.n_cast_sets * nQ;
@@ -1092,6 +1095,7 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
     ca.dynAabb0 = e->d_dynAabb.p; ca.dynAabb1 = sep1 ? e->d_dynAabb1.p : e->d_dynAabb.p;
     ca.dynSph0 = e->d_dynSph.p;
     ca.pretest = e->pretest;
+    ca.defer_exact = 0;
     ca.dbg = getenv("TOHC_BP_DBG") ? atoi(getenv("TOHC_BP_DBG")) : 0;
     // Who scans what (k_broadphase_unit's comment): when all a unit's box tests fit a few dozen rounds of one wavefront
     // (a small world; in "poses" mode every child moves and there is no static table), a wavefront per unit takes them
@@ -1109,8 +1113,15 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
     }
     ca.dyn_elsewhere = unitDyn ? 1 : 0;
     if (!unitAll) {
+      // the exact stage of the pre-test in a kernel of its own, a lane per pair (k_exact), when there are enough
+      // wavefronts for it to matter
+      ca.defer_exact = (e->defer_exact && ca.pretest && TOHC_BP_EXACT && ca.dbg == 0) ? 1 : 0;
       if (cp.cast) hipLaunchKernelGGL((k_broadphase<true>), dim3((unsigned)blocks), dim3(TOHC_BP_THREADS), 0, s, ca);
       else hipLaunchKernelGGL((k_broadphase<false>), dim3((unsigned)blocks), dim3(TOHC_BP_THREADS), 0, s, ca);
+      if (ca.defer_exact) {
+        if (cp.cast) hipLaunchKernelGGL((k_exact<true>), dim3(TOHC_EXACT_GRID), dim3(64), 0, s, ca);
+        else hipLaunchKernelGGL((k_exact<false>), dim3(TOHC_EXACT_GRID), dim3(64), 0, s, ca);
+      }
     }
     HIPCHK(hipEventRecord(ev[3], s));
     const int gridN = 256 * 8;

@@ -96,7 +96,8 @@ struct CounterShard {
   unsigned int n_pen_sups;    // Minkowski support queries of GJK2 / the Distance fall-back in k_pen
   unsigned int n_epa_sups;    // the same in k_epa (one per EPA iteration, plus EncloseOrigin's)
   unsigned int n_epa_redone;  // EPA runs repeated on the full pools
-  unsigned int pad[23];
+  unsigned int n_exact;       // pairs k_broadphase's sphere stage leaves for k_exact (NarrowArgs.cands)
+  unsigned int pad[22];
 };
 struct Counters {
   CounterShard sh[TOHC_NSHARD];
@@ -170,6 +171,38 @@ __device__ __forceinline__ unsigned int qlocate(const QPrefix &p, unsigned int s
   for (int k = 1; k < TOHC_NSHARD; ++k)
     if (k == (int)sh) st = p.start[k];
   return sh * segCap + (i - st);
+}
+
+// One queue slot for every lane that wants one, with ONE atomic per wavefront: the lanes that are active here vote,
+// the first of them reserves for all.  Call it with all lanes of a (possibly divergent) branch, `want` false for the
+// lanes that only take part in the vote.  Blocks of the lane-per-pair kernels are single wavefronts.
+__device__ __forceinline__ unsigned int waveSlot(unsigned int *ctr, bool want) {
+  const unsigned long long m = __ballot(want);
+  unsigned int slot = 0;
+  if (want) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int leader = (int)__builtin_ctzll(m);
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(ctr, (unsigned int)__popcll(m));
+    base = __shfl(base, leader);
+    slot = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+  }
+  return slot;
+}
+// sum of `v` over the wavefront's lanes, added to *ctr with one atomic (call with every lane of the wavefront)
+__device__ __forceinline__ void waveAdd(unsigned int *ctr, unsigned int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(ctr, v);
+}
+
+// the exact stage of the pre-test: the gap between the two shapes along `dir` (other child -> query origin; eA = the
+// query's reach along -dir, mq its margin) is a lower bound of their distance; true = provably more than lim apart
+__device__ __forceinline__ bool exactBeyond(V3 dir, float dl2, V3 oq, float eA, float mq, const Cvx<1> &cx, const Xf &tx, float lim) {
+  const float eB = reachNV(cx, mulVM(dir, tx.b));
+  const float delta = dot(dir, oq - tx.o) - eA - eB;
+  const float limm = lim + (mq + cvxMargin<1>(cx));
+  return (delta > 0.0f) && (delta * delta > (limm * limm) * dl2);
 }
 
 // the sphere stage of k_broadphase's pre-test for a child that moves: what CullSph holds for one that never does, at this pose
@@ -351,6 +384,7 @@ struct NarrowArgs {
   const double *linkZ;    // [n_sets][n_links][3]: every link's joint axis in the world (k_fk), null in poses mode
   const double *dofs;     // [n_sets][K]
   PairRec *pairs;
+  PairRec *cands;         // k_broadphase -> k_exact: what the sphere stage of the pre-test passes (pad = the other child's slot + 1 if it moves)
   EpaRec *epaq;
   PenRec *penq;
   unsigned int *distq;    // positions in epaq of the pairs for the Distance fall-back (k_tail_pen -> the extra blocks of k_tail_epa)
@@ -425,6 +459,7 @@ struct CullArgs {
   const CullSph *dynSph0;   // [n_sets][moving children]: bounding spheres at the (first) pose of each set
   int pretest;
   int dyn_elsewhere;   // k_broadphase: the moving children are k_broadphase_unit's; k_broadphase_unit: 1 = it also takes the static ones
+  int defer_exact;     // k_broadphase: the exact stage of the pre-test runs in k_exact, on full wavefronts (NarrowArgs.cands)
   int dbg;   // timing experiments only (TOHC_BP_DBG): 1 = count the box-test survivors and drop them, 2 = stage 1 only, drop the rest
 };
 template <bool CAST>
@@ -504,36 +539,36 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
         const float dl2 = len2(dir);
         if (dl2 > 1.0e-12f) {
           const float dl = sqrtf(dl2);
-          const V3 pA = xfApply(tq, supNV<1>(cq, mulVM(-dir, tq.b)));
+          const float eA = reachNV(cq, mulVM(-dir, tq.b));   // how far the query reaches towards the other child
           const float mq = cvxMargin<1>(cq);   // a plain sphere is its centre + this much (0 for everything else)
-          const float deltaS = dot(dir, pA - c) - (rad + mq) * dl;
+          const float deltaS = dl2 - eA - (rad + mq) * dl;
           if ((deltaS > 0.0f && deltaS > lim * dl) || ca.dbg == 2) {
             keep = false;
-          } else if (TOHC_BP_EXACT) {
+          } else if (TOHC_BP_EXACT && !ca.defer_exact) {
             const ChildDesc dx = sc.child_desc[x];
             // (a child that never moves: its pose straight from the static table, no look-up of its slot first)
             const Xf tx = xDyn ? ldXf(a.dynXf0 + ((size_t)set0 * dm.n_dyn_children + xSlot) * 12) : ldXf(sc.stat_xf + 12 * x);
             Cvx<1> cx;
             cvxLoad<1>(cx, dx.kind, mk(dx.dims[0], dx.dims[1], dx.dims[2]), sc.vx, sc.vy, sc.vz, sc.v4, dx.voff, dx.vcnt);
-            const V3 qB = xfApply(tx, supNV<1>(cx, mulVM(dir, tx.b)));
-            const float delta = dot(dir, pA - qB);
-            const float limm = lim + (mq + cvxMargin<1>(cx));
-            keep = !((delta > 0.0f) && (delta * delta > (limm * limm) * dl2));
+            keep = !exactBeyond(dir, dl2, tq.o, eA, mq, cx, tx, lim);
           }
         }
       }
+      // survivors: to k_gjk's pair list -- or, with the exact stage deferred, to k_exact's list: only one lane in ten gets
+      // this far, and run here the exact stage is ~250 instructions of every wavefront for the four or five lanes that
+      // need it; k_exact runs it on full wavefronts
       const unsigned long long m = __ballot(keep);
       const unsigned int cnt = (unsigned int)__popcll(m);
       if (cnt > 0) {
         unsigned int base = 0;
-        if (lane == 0) base = atomicAdd(&a.cnt->sh[shard].n_pairs, cnt);
+        if (lane == 0) base = atomicAdd(ca.defer_exact ? &a.cnt->sh[shard].n_exact : &a.cnt->sh[shard].n_pairs, cnt);
         base = __shfl(base, 0);
         if (keep) {
           const unsigned int pos = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
           if (pos < cp.seg_cap) {
             PairRec p;
-            p.set = cs; p.q = q; p.x = x; p.pad = 0;
-            a.pairs[(size_t)shard * cp.seg_cap + pos] = p;
+            p.set = cs; p.q = q; p.x = x; p.pad = xDyn ? xSlot + 1 : 0;
+            (ca.defer_exact ? a.cands : a.pairs)[(size_t)shard * cp.seg_cap + pos] = p;
           } else {
             a.cnt->overflow = 1;
           }
@@ -610,6 +645,60 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
 }
 
 // -----------------------------------------------------------------------------------------------------------------
+// k_exact: the exact stage of k_broadphase's pre-test, ONE LANE per pair the sphere stage passed (NarrowArgs.cands).
+// Same direction (query origin - the other child's bounding-sphere centre, read from the same record), same support
+// points, same test as the stage inside the broadphase kernels: the pair list k_gjk gets holds the same pairs.
+// -----------------------------------------------------------------------------------------------------------------
+#define TOHC_EXACT_GRID 4096
+template <bool CAST>
+__global__ void __launch_bounds__(64) k_exact(CullArgs ca) {
+  const NarrowArgs &a = ca.a;
+  const DevScene &sc = a.sc;
+  const DynMap &dm = a.dm;
+  const CallParams &cp = a.cp;
+  const int lane = threadIdx.x;
+  const int shard = blockIdx.x % TOHC_NSHARD;
+  QPrefix pre;
+  qprefix(&a.cnt->sh[0].n_exact, cp.seg_cap, pre);
+  const unsigned int n = pre.start[TOHC_NSHARD];
+  const float lim = cp.d * 1.01f + 1.0e-4f;
+  for (unsigned int i0 = blockIdx.x * 64u; i0 < n; i0 += gridDim.x * 64u) {   // (wave-uniform)
+    const unsigned int i = i0 + lane;
+    bool keep = i < n;
+    PairRec p;
+    p.set = p.q = p.x = p.pad = 0;
+    if (keep) {
+      p = a.cands[qlocate(pre, cp.seg_cap, i)];
+      int set0, set1;
+      castSets(cp, p.set, set0, set1);
+      const int xSlot = p.pad - 1;
+      const CullSph sx = xSlot >= 0 ? ca.dynSph0[(size_t)set0 * dm.n_dyn_children + xSlot] : sc.stat_sph[p.x];
+      const ChildDesc dx = sc.child_desc[p.x];
+      const Xf tx = xSlot >= 0 ? ldXf(a.dynXf0 + ((size_t)set0 * dm.n_dyn_children + xSlot) * 12) : ldXf(sc.stat_xf + 12 * p.x);
+      Cvx<1> cq;
+      Xf tq;
+      loadSide<1>(a, p.q, sc.child_desc[p.q], set0, set1, CAST, cq, tq);
+      const V3 dir = tq.o - mk(sx.c[0], sx.c[1], sx.c[2]);
+      const float dl2 = len2(dir);
+      if (dl2 > 1.0e-12f) {
+        Cvx<1> cx;
+        cvxLoad<1>(cx, dx.kind, mk(dx.dims[0], dx.dims[1], dx.dims[2]), sc.vx, sc.vy, sc.vz, sc.v4, dx.voff, dx.vcnt);
+        keep = !exactBeyond(dir, dl2, tq.o, reachNV(cq, mulVM(-dir, tq.b)), cvxMargin<1>(cq), cx, tx, lim);
+      }
+    }
+    const unsigned int pos = waveSlot(&a.cnt->sh[shard].n_pairs, keep);
+    if (keep) {
+      if (pos < cp.seg_cap) {
+        p.pad = 0;
+        a.pairs[(size_t)shard * cp.seg_cap + pos] = p;
+      } else {
+        a.cnt->overflow = 1;
+      }
+    }
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------------
 // k_broadphase_unit: ONE WAVEFRONT per unit for everything a short list of boxes has to offer -- the moving children
 // (a robot's own links: 45 boxes on config 4, where a wavefront per (unit, query child) spent a quarter of its time on
 // one under-filled round of them and its set-up), and in a small world (a table, a kitchen: the multi-start
@@ -675,9 +764,9 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase_u
         const float dl2 = len2(dir);
         if (dl2 > 1.0e-12f) {
           const float dl = sqrtf(dl2);
-          const V3 pA = xfApply(tq, supNV<1>(cq, mulVM(-dir, tq.b)));
+          const float eA = reachNV(cq, mulVM(-dir, tq.b));
           const float mq = cvxMargin<1>(cq);
-          const float deltaS = dot(dir, pA - c) - (rad + mq) * dl;
+          const float deltaS = dl2 - eA - (rad + mq) * dl;
           if ((deltaS > 0.0f && deltaS > lim * dl) || ca.dbg == 2) {
             keep = false;
           } else if (TOHC_BP_EXACT) {
@@ -685,10 +774,7 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase_u
             const Xf tx = xDyn ? ldXf(a.dynXf0 + ((size_t)set0 * dm.n_dyn_children + xSlot) * 12) : ldXf(sc.stat_xf + 12 * x);
             Cvx<1> cx;
             cvxLoad<1>(cx, dx.kind, mk(dx.dims[0], dx.dims[1], dx.dims[2]), sc.vx, sc.vy, sc.vz, sc.v4, dx.voff, dx.vcnt);
-            const V3 qB = xfApply(tx, supNV<1>(cx, mulVM(dir, tx.b)));
-            const float delta = dot(dir, pA - qB);
-            const float limm = lim + (mq + cvxMargin<1>(cx));
-            keep = !((delta > 0.0f) && (delta * delta > (limm * limm) * dl2));
+            keep = !exactBeyond(dir, dl2, tq.o, eA, mq, cx, tx, lim);
           }
         }
       }
@@ -910,28 +996,6 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs sa) {
   }
 }
 
-// One queue slot for every lane that wants one, with ONE atomic per wavefront: the lanes that are active here vote,
-// the first of them reserves for all.  Call it with all lanes of a (possibly divergent) branch, `want` false for the
-// lanes that only take part in the vote.  Blocks of the lane-per-pair kernels are single wavefronts.
-__device__ __forceinline__ unsigned int waveSlot(unsigned int *ctr, bool want) {
-  const unsigned long long m = __ballot(want);
-  unsigned int slot = 0;
-  if (want) {
-    const int lane = (int)(threadIdx.x & 63);
-    const int leader = (int)__builtin_ctzll(m);
-    unsigned int base = 0;
-    if (lane == leader) base = atomicAdd(ctr, (unsigned int)__popcll(m));
-    base = __shfl(base, leader);
-    slot = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
-  }
-  return slot;
-}
-// sum of `v` over the wavefront's lanes, added to *ctr with one atomic (call with every lane of the wavefront)
-__device__ __forceinline__ void waveAdd(unsigned int *ctr, unsigned int v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-  if ((threadIdx.x & 63) == 0 && v) atomicAdd(ctr, v);
-}
 // Bullet's output filter [gjk:430-449] + the collector's distance filter (bullet_collision_checker.cpp:401)
 __device__ __forceinline__ bool isContact(const NarrowArgs &a, const GjkState &st, float md2, PairOut &o) {
   gjkOutput(st, md2, o);

@@ -273,6 +273,37 @@ TOHC_DEV V3 supWithMarginNV(const Cvx<G> &c, V3 d) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The engine's own pre-test (k_broadphase / k_exact; nothing of Bullet's) needs no support POINT, only how far a shape
+// reaches along a direction: max over the shape of dot(d, p), local frame.  That is a third of the instructions of the
+// support query per hull vertex (mul, fma, fma, max against three products, two sums, a compare and four selects), and
+// the value may round differently from dot(d, supNV(d)): the pre-test's guard band (1 % of d + 0.1 mm) is there for that.
+// The shape is supNV's: without its margin when plain, the swept hull of both poses (a sphere with its radius) when cast.
+// ---------------------------------------------------------------------------------------------------------------
+#if defined(__HIPCC__)
+TOHC_DEV float plainReach(const Cvx<1> &c, V3 d, bool withRadius) {
+  if (c.kind == KIND_SPHERE) return withRadius ? c.dims.x * sqrtf(len2(d)) : 0.0f;
+  if (c.kind == KIND_BOX) return fmaf(fabsf(d.x), c.dims.x, fmaf(fabsf(d.y), c.dims.y, fabsf(d.z) * c.dims.z));
+  if (c.kind == KIND_CYLZ) return fmaf(c.dims.x, sqrtf(fmaf(d.x, d.x, d.y * d.y)), fabsf(d.z) * c.dims.z);
+  float best = -INFINITY;
+  const int last = c.n - 1;
+  for (int i0 = 0; i0 < c.n; i0 += 8) {
+    F4 p[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k] = c.v[min(i0 + k, last)];   // past the end: the last vertex again
+#pragma unroll
+    for (int k = 0; k < 8; ++k) best = fmaxf(best, fmaf(p[k].x, d.x, fmaf(p[k].y, d.y, p[k].z * d.z)));
+  }
+  return best;
+}
+TOHC_DEV float reachNV(const Cvx<1> &c, V3 d) {
+  if (!c.cast) return plainReach(c, d, false);
+  const float e0 = plainReach(c, d, true);
+  const float e1 = plainReach(c, mulVM(d, c.t01.b), true) + dot(d, c.t01.o);
+  return fmaxf(e0, e1);
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
 // btVoronoiSimplexSolver [vss]; arrays are only ever indexed with compile-time constants (select chains), so they
 // stay in registers
 // ---------------------------------------------------------------------------------------------------------------
