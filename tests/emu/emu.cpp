@@ -17,6 +17,8 @@ struct World {
   std::vector<Shape> shapes;
   std::vector<float> vx, vy, vz;
   std::vector<F4> v4;
+  std::vector<float> v8;
+  std::vector<int> voff8;
   std::vector<int> child_shape;
   std::vector<Xf> child_T;
   std::vector<int> off, cnt, compound, group;
@@ -31,7 +33,7 @@ float safeMargin(float cur, float x, float y, float z) {
 }
 void load(const World *w, int child, Cvx<1> &c) {
   const Shape &s = w->shapes[w->child_shape[child]];
-  cvxLoad<1>(c, s.kind, s.dims, w->vx.data(), w->vy.data(), w->vz.data(), w->v4.data(), s.voff, s.n);
+  cvxLoad<1>(c, s.kind, s.dims, w->vx.data(), w->vy.data(), w->vz.data(), w->v4.data(), s.voff, s.n, w->v8.data(), w->voff8[w->child_shape[child]]);
 }
 Xf childWorld(const World *w, int obj, int c, const Xf &T) { return w->compound[obj] ? xfMul(T, w->child_T[w->off[obj] + c]) : T; }
 long g_iter_hist[64];
@@ -158,6 +160,11 @@ void *emu_create(const ora_scene *sc) {
   for (size_t i = 0; i < w->vx.size(); ++i) { F4 p; p.x = w->vx[i]; p.y = w->vy[i]; p.z = w->vz[i]; p.w = 0; w->v4.push_back(p); }
   { F4 z; z.x = z.y = z.z = z.w = 0; w->v4.resize(w->v4.size() + 64, z); }
   w->vx.resize(w->vx.size() + 64); w->vy.resize(w->vy.size() + 64); w->vz.resize(w->vz.size() + 64);
+  {
+    std::vector<int> kind, voff, vcnt;
+    for (const Shape &s : w->shapes) { kind.push_back(s.kind); voff.push_back(s.voff); vcnt.push_back(s.n); }
+    blockVertices(w->vx.data(), w->vy.data(), w->vz.data(), (int)w->shapes.size(), kind.data(), voff.data(), vcnt.data(), w->v8, w->voff8);
+  }
   for (int i = 0; i < sc->n_children; ++i) { w->child_shape.push_back(sc->child_shape[i]); w->child_T.push_back(xfFrom7(sc->child_T + 7 * i)); }
   for (int i = 0; i < sc->n_objects; ++i) {
     w->off.push_back(sc->obj_child_off[i]); w->cnt.push_back(sc->obj_child_cnt[i]);

@@ -86,6 +86,8 @@ struct tohc_engine {
   DBuf<int> d_shape_kind, d_shape_voff, d_shape_vcnt, d_child_shape, d_child_obj, d_child_idx, d_obj_off, d_obj_cnt, d_obj_compound, d_obj_group;
   DBuf<float> d_shape_dims, d_shape_lmin, d_shape_lmax, d_vx, d_vy, d_vz, d_child_localT, d_stat_xf, d_stat_aabb;
   DBuf<F4> d_v4;
+  DBuf<float> d_v8;              // blocked hull vertices (tohc_narrow.h, Cvx<1>)
+  std::vector<int> h_shape_voff8;
   DBuf<unsigned char> d_allowed;
   DBuf<ChildDesc> d_child_desc;
   DBuf<CullSph> d_stat_sph;
@@ -407,7 +409,7 @@ static int refreshStatic(tohc_engine *e) {
       memset(&d, 0, sizeof d);
       const int sh = e->h_child_shape[c], obj = e->h_child_obj[c];
       d.obj = obj; d.idx = e->h_child_idx[c]; d.kind = e->h_shape_kind[sh]; d.compound = e->h_obj_compound[obj];
-      d.voff = e->h_shape_voff[sh]; d.vcnt = e->h_shape_vcnt[sh];
+      d.voff = e->h_shape_voff[sh]; d.vcnt = e->h_shape_vcnt[sh]; d.voff8 = e->h_shape_voff8[sh];
       d.dynR = e->h_child_dynR.empty() ? -1 : e->h_child_dynR[c];
       d.group = e->h_obj_group[obj];
       for (int k = 0; k < 3; ++k) d.dims[k] = e->h_shape_dims[3 * sh + k];
@@ -627,6 +629,9 @@ int tohc_upload_scene(tohc_engine *e, int n_shapes, const int32_t *shape_kind, c
     std::vector<F4> p4((size_t)n_verts + 64);
     for (size_t i = 0; i < p4.size(); ++i) { p4[i].x = px[i]; p4[i].y = py[i]; p4[i].z = pz[i]; p4[i].w = 0.f; }
     HIPCHK(upload(e->d_v4, p4, s));
+    std::vector<float> v8;
+    blockVertices(px.data(), py.data(), pz.data(), n_shapes, shape_kind, shape_voff, shape_vcnt, v8, e->h_shape_voff8);
+    HIPCHK(upload(e->d_v8, v8, s));
     HIPCHK(hipStreamSynchronize(s));
   }
   HIPCHK(upload(e->d_child_shape, e->h_child_shape, s)); HIPCHK(upload(e->d_child_obj, e->h_child_obj, s)); HIPCHK(upload(e->d_child_idx, e->h_child_idx, s));
@@ -794,7 +799,7 @@ static DevScene devScene(tohc_engine *e) {
   s.n_shapes = e->n_shapes; s.n_children = e->n_children; s.n_objects = e->n_objects;
   s.shape_kind = e->d_shape_kind.p; s.shape_voff = e->d_shape_voff.p; s.shape_vcnt = e->d_shape_vcnt.p;
   s.shape_dims = e->d_shape_dims.p; s.shape_lmin = e->d_shape_lmin.p; s.shape_lmax = e->d_shape_lmax.p;
-  s.vx = e->d_vx.p; s.vy = e->d_vy.p; s.vz = e->d_vz.p; s.v4 = e->d_v4.p;
+  s.vx = e->d_vx.p; s.vy = e->d_vy.p; s.vz = e->d_vz.p; s.v4 = e->d_v4.p; s.v8 = e->d_v8.p;
   s.child_shape = e->d_child_shape.p; s.child_obj = e->d_child_obj.p; s.child_idx = e->d_child_idx.p; s.child_localT = e->d_child_localT.p;
   s.obj_off = e->d_obj_off.p; s.obj_cnt = e->d_obj_cnt.p; s.obj_compound = e->d_obj_compound.p; s.obj_group = e->d_obj_group.p;
   s.allowed = e->d_allowed.p; s.stat_xf = e->d_stat_xf.p; s.stat_aabb = e->d_stat_aabb.p; s.child_desc = e->d_child_desc.p; s.stat_sph = e->d_stat_sph.p;
@@ -1116,8 +1121,13 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
       // the exact stage of the pre-test in a kernel of its own, a lane per pair (k_exact), when there are enough
       // wavefronts for it to matter
       ca.defer_exact = (e->defer_exact && ca.pretest && TOHC_BP_EXACT && ca.dbg == 0) ? 1 : 0;
-      if (cp.cast) hipLaunchKernelGGL((k_broadphase<true>), dim3((unsigned)blocks), dim3(TOHC_BP_THREADS), 0, s, ca);
-      else hipLaunchKernelGGL((k_broadphase<false>), dim3((unsigned)blocks), dim3(TOHC_BP_THREADS), 0, s, ca);
+      if (ca.defer_exact) {
+        if (cp.cast) hipLaunchKernelGGL((k_broadphase<true, true>), dim3((unsigned)blocks), dim3(TOHC_BP_THREADS), 0, s, ca);
+        else hipLaunchKernelGGL((k_broadphase<false, true>), dim3((unsigned)blocks), dim3(TOHC_BP_THREADS), 0, s, ca);
+      } else {
+        if (cp.cast) hipLaunchKernelGGL((k_broadphase<true, false>), dim3((unsigned)blocks), dim3(TOHC_BP_THREADS), 0, s, ca);
+        else hipLaunchKernelGGL((k_broadphase<false, false>), dim3((unsigned)blocks), dim3(TOHC_BP_THREADS), 0, s, ca);
+      }
       if (ca.defer_exact) {
         if (cp.cast) hipLaunchKernelGGL((k_exact<true>), dim3(TOHC_EXACT_GRID), dim3(64), 0, s, ca);
         else hipLaunchKernelGGL((k_exact<false>), dim3(TOHC_EXACT_GRID), dim3(64), 0, s, ca);

@@ -30,7 +30,7 @@ struct ChildDesc {   // 64 B = one cache line per child: cuts the dependent-load
   int voff, vcnt;
   int dynR, group;   // slot among the robot's moving children (robot mode) or -1; the object's filter group
   float dims[3];
-  float pad2;
+  int voff8;         // a hull's first block in DevScene::v8
   float sph[4];      // bounding sphere in the child's frame: centre of its local box, radius (slightly inflated)
 };
 struct CullSph {     // 32 B per child: all the sphere stage of the pre-test needs of a child that never moves
@@ -43,7 +43,8 @@ struct DevScene {
   const int *shape_kind, *shape_voff, *shape_vcnt;
   const float *shape_dims, *shape_lmin, *shape_lmax;  // [n][3]
   const float *vx, *vy, *vz;
-  const F4 *v4;                                       // the same vertices as 16-byte records (lane-per-pair GJK)
+  const F4 *v4;                                       // the same vertices as 16-byte records (groups of 4 / 8 lanes)
+  const float *v8;                                    // ... and in blocks of 8 (tohc_narrow.h, Cvx<1>): the lane-per-pair kernels' table
   const int *child_shape, *child_obj, *child_idx;
   const float *child_localT;                          // [n][12] rows of the 3x3 then origin
   const int *obj_off, *obj_cnt, *obj_compound, *obj_group;
@@ -346,7 +347,7 @@ __global__ void __launch_bounds__(256) k_ray(RayArgs ra) {
   const int ray = (int)(i % ra.n_rays), child = (int)(i / ra.n_rays);
   const ChildDesc cd = ra.sc.child_desc[child];
   Cvx<1> cx;
-  cvxLoad<1>(cx, cd.kind, mk(cd.dims[0], cd.dims[1], cd.dims[2]), ra.sc.vx, ra.sc.vy, ra.sc.vz, ra.sc.v4, cd.voff, cd.vcnt);
+  cvxLoad<1>(cx, cd.kind, mk(cd.dims[0], cd.dims[1], cd.dims[2]), ra.sc.vx, ra.sc.vy, ra.sc.vz, ra.sc.v4, cd.voff, cd.vcnt, ra.sc.v8, cd.voff8);
   const int slot = ra.dm.child_dyn[child];
   const Xf tx = slot >= 0 ? ldXf(ra.dynXf + (size_t)slot * 12) : ldXf(ra.sc.stat_xf + 12 * child);
   const F4 a = reinterpret_cast<const F4 *>(ra.rays)[2 * ray], b = reinterpret_cast<const F4 *>(ra.rays)[2 * ray + 1];
@@ -421,7 +422,7 @@ __device__ __forceinline__ Xf childXf(const NarrowArgs &a, const float *dyn, int
 template <int G>
 // (slot: the child's slot in the pose tables when the caller knows it, -1 if it never moves, -2 = look it up)
 __device__ __forceinline__ void loadSide(const NarrowArgs &a, int child, const ChildDesc &cd, int set0, int set1, bool cast, Cvx<G> &c, Xf &t0, int slot = -2) {
-  cvxLoad<G>(c, cd.kind, mk(cd.dims[0], cd.dims[1], cd.dims[2]), a.sc.vx, a.sc.vy, a.sc.vz, a.sc.v4, cd.voff, cd.vcnt);
+  cvxLoad<G>(c, cd.kind, mk(cd.dims[0], cd.dims[1], cd.dims[2]), a.sc.vx, a.sc.vy, a.sc.vz, a.sc.v4, cd.voff, cd.vcnt, a.sc.v8, cd.voff8);
   if (slot == -2) slot = a.dm.child_dyn[child];
   t0 = slot >= 0 ? ldXf(a.dynXf0 + ((size_t)set0 * a.dm.n_dyn_children + slot) * 12) : ldXf(a.sc.stat_xf + 12 * child);
   if (cast) {
@@ -462,9 +463,10 @@ struct CullArgs {
   int defer_exact;     // k_broadphase: the exact stage of the pre-test runs in k_exact, on full wavefronts (NarrowArgs.cands)
   int dbg;   // timing experiments only (TOHC_BP_DBG): 1 = count the box-test survivors and drop them, 2 = stage 1 only, drop the rest
 };
-template <bool CAST>
+// DEFER: the exact stage of the pre-test is k_exact's (ca.defer_exact), and this kernel holds no code for it
+template <bool CAST, bool DEFER>
 #ifndef TOHC_BP_WAVES
-#define TOHC_BP_WAVES 3   // 168 VGPRs instead of 179: three resident waves per SIMD (4 spills: measured slower; 2: 8 % slower)
+#define TOHC_BP_WAVES 5   // <= 96 VGPRs: five resident waves per SIMD instead of four hide more of the load chain (6: spills, slower)
 #endif
 __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(CullArgs ca) {
   const NarrowArgs &a = ca.a;
@@ -544,12 +546,12 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
           const float deltaS = dl2 - eA - (rad + mq) * dl;
           if ((deltaS > 0.0f && deltaS > lim * dl) || ca.dbg == 2) {
             keep = false;
-          } else if (TOHC_BP_EXACT && !ca.defer_exact) {
+          } else if (TOHC_BP_EXACT && !DEFER) {
             const ChildDesc dx = sc.child_desc[x];
             // (a child that never moves: its pose straight from the static table, no look-up of its slot first)
             const Xf tx = xDyn ? ldXf(a.dynXf0 + ((size_t)set0 * dm.n_dyn_children + xSlot) * 12) : ldXf(sc.stat_xf + 12 * x);
             Cvx<1> cx;
-            cvxLoad<1>(cx, dx.kind, mk(dx.dims[0], dx.dims[1], dx.dims[2]), sc.vx, sc.vy, sc.vz, sc.v4, dx.voff, dx.vcnt);
+            cvxLoad<1>(cx, dx.kind, mk(dx.dims[0], dx.dims[1], dx.dims[2]), sc.vx, sc.vy, sc.vz, sc.v4, dx.voff, dx.vcnt, sc.v8, dx.voff8);
             keep = !exactBeyond(dir, dl2, tq.o, eA, mq, cx, tx, lim);
           }
         }
@@ -561,14 +563,14 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
       const unsigned int cnt = (unsigned int)__popcll(m);
       if (cnt > 0) {
         unsigned int base = 0;
-        if (lane == 0) base = atomicAdd(ca.defer_exact ? &a.cnt->sh[shard].n_exact : &a.cnt->sh[shard].n_pairs, cnt);
+        if (lane == 0) base = atomicAdd(DEFER ? &a.cnt->sh[shard].n_exact : &a.cnt->sh[shard].n_pairs, cnt);
         base = __shfl(base, 0);
         if (keep) {
           const unsigned int pos = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
           if (pos < cp.seg_cap) {
             PairRec p;
             p.set = cs; p.q = q; p.x = x; p.pad = xDyn ? xSlot + 1 : 0;
-            (ca.defer_exact ? a.cands : a.pairs)[(size_t)shard * cp.seg_cap + pos] = p;
+            (DEFER ? a.cands : a.pairs)[(size_t)shard * cp.seg_cap + pos] = p;
           } else {
             a.cnt->overflow = 1;
           }
@@ -682,7 +684,7 @@ __global__ void __launch_bounds__(64) k_exact(CullArgs ca) {
       const float dl2 = len2(dir);
       if (dl2 > 1.0e-12f) {
         Cvx<1> cx;
-        cvxLoad<1>(cx, dx.kind, mk(dx.dims[0], dx.dims[1], dx.dims[2]), sc.vx, sc.vy, sc.vz, sc.v4, dx.voff, dx.vcnt);
+        cvxLoad<1>(cx, dx.kind, mk(dx.dims[0], dx.dims[1], dx.dims[2]), sc.vx, sc.vy, sc.vz, sc.v4, dx.voff, dx.vcnt, sc.v8, dx.voff8);
         keep = !exactBeyond(dir, dl2, tq.o, reachNV(cq, mulVM(-dir, tq.b)), cvxMargin<1>(cq), cx, tx, lim);
       }
     }
@@ -773,7 +775,7 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase_u
             const ChildDesc dx = sc.child_desc[x];
             const Xf tx = xDyn ? ldXf(a.dynXf0 + ((size_t)set0 * dm.n_dyn_children + xSlot) * 12) : ldXf(sc.stat_xf + 12 * x);
             Cvx<1> cx;
-            cvxLoad<1>(cx, dx.kind, mk(dx.dims[0], dx.dims[1], dx.dims[2]), sc.vx, sc.vy, sc.vz, sc.v4, dx.voff, dx.vcnt);
+            cvxLoad<1>(cx, dx.kind, mk(dx.dims[0], dx.dims[1], dx.dims[2]), sc.vx, sc.vy, sc.vz, sc.v4, dx.voff, dx.vcnt, sc.v8, dx.voff8);
             keep = !exactBeyond(dir, dl2, tq.o, eA, mq, cx, tx, lim);
           }
         }

@@ -116,16 +116,40 @@ struct Cvx {
 };
 
 // G = 1: the hull stays in memory (64 pairs per wavefront leave no registers for vertices); a support query is a scan
+// The table it scans is BLOCKED: per hull, blocks of 8 vertices stored as x[8] y[8] z[8] (96 bytes, six 16-byte loads),
+// the last block filled up with copies of the hull's last vertex -- a copy never wins the strict '>' of the scan, so no
+// lane of the compare needs a mask, and two vertices' products and sums go through one packed instruction each.
 template <>
 struct Cvx<1> {
   int kind, cast, n;
   V3 dims;
-  const F4 *v;
+  const float *vb;   // the hull's first block
   Xf t01;
 };
+#define TOHC_VBLOCK 24   // floats per block of 8 vertices
+// the blocked table of a scene's hulls (host): voff8[shape] = first block of the shape's vertices
+template <class VecF, class VecI>
+inline void blockVertices(const float *vx, const float *vy, const float *vz, int n_shapes, const int *kind, const int *voff, const int *vcnt, VecF &v8,
+                          VecI &voff8) {
+  v8.clear(); voff8.assign(n_shapes, 0);
+  for (int sh = 0; sh < n_shapes; ++sh) {
+    if (kind[sh] != 1 /* KIND_HULL */ || vcnt[sh] <= 0) continue;
+    voff8[sh] = (int)(v8.size() / TOHC_VBLOCK);
+    for (int i0 = 0; i0 < vcnt[sh]; i0 += 8) {
+      const size_t b = v8.size();
+      v8.resize(b + TOHC_VBLOCK);
+      for (int k = 0; k < 8; ++k) {
+        const int i = voff[sh] + (i0 + k < vcnt[sh] ? i0 + k : vcnt[sh] - 1);
+        v8[b + k] = vx[i]; v8[b + 8 + k] = vy[i]; v8[b + 16 + k] = vz[i];
+      }
+    }
+  }
+  v8.resize(v8.size() + TOHC_VBLOCK, 0.0f);   // (never empty)
+}
 
 template <int G>
-TOHC_DEV void cvxLoad(Cvx<G> &c, int kind, V3 dims, const float *vx, const float *vy, const float *vz, const F4 *v4, int voff, int n) {
+TOHC_DEV void cvxLoad(Cvx<G> &c, int kind, V3 dims, const float *vx, const float *vy, const float *vz, const F4 *v4, int voff, int n,
+                      const float * = nullptr, int = 0) {
   c.kind = kind;
   c.cast = 0;
   c.n = n;
@@ -149,12 +173,13 @@ TOHC_DEV void cvxLoad(Cvx<G> &c, int kind, V3 dims, const float *vx, const float
 }
 
 template <>
-TOHC_DEV void cvxLoad<1>(Cvx<1> &c, int kind, V3 dims, const float *, const float *, const float *, const F4 *v4, int voff, int n) {
+TOHC_DEV void cvxLoad<1>(Cvx<1> &c, int kind, V3 dims, const float *, const float *, const float *, const F4 *, int, int n, const float *v8,
+                         int voff8) {
   c.kind = kind;
   c.cast = 0;
   c.n = n;
   c.dims = dims;
-  c.v = v4 + voff;
+  c.vb = v8 + (size_t)voff8 * TOHC_VBLOCK;
 }
 
 TOHC_DEV float fsel(float a, float b, float c) { return a >= 0 ? b : c; }  // btScalar.h:468-473
@@ -192,24 +217,36 @@ TOHC_DEV V3 hullMaxDot(const Cvx<G> &c, V3 d) {
   return mk(Grp<G>::bcast(sx, src), Grp<G>::bcast(sy, src), Grp<G>::bcast(sz, src));
 }
 
-// The scan reads 8 vertices ahead of the compare chain: with one load per step the loop would be a chain of L2 round
-// trips (~300 cycles each), which is what a lane-per-pair support query costs otherwise.  The vertex table is padded
-// with 64 records, so reading up to 7 past a hull's end stays in bounds; those lanes of the compare are masked.
+// The scan takes a block of 8 vertices per step (six 16-byte loads issued together: with one load per vertex the loop
+// would be a chain of L2 round trips, ~300 cycles each).  Products and sums are Bullet's, unfused, in its order
+// ((x dx + y dy) + z dz); two vertices share each packed multiply / add.
+#if defined(__HIPCC__)
+typedef float Pk2 __attribute__((ext_vector_type(2)));
+#endif
 template <>
 TOHC_DEV V3 hullMaxDot<1>(const Cvx<1> &c, V3 d) {
   float best = -INFINITY;
   V3 bv = mk(0, 0, 0);
   for (int i0 = 0; i0 < c.n; i0 += 8) {
-    F4 p[8];
+    const F4 *b = reinterpret_cast<const F4 *>(c.vb + 3 * i0);
+    const F4 xa = b[0], xb = b[1], ya = b[2], yb = b[3], za = b[4], zb = b[5];
+    const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+    const float ys[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+    const float zs[8] = {za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) p[k] = c.v[i0 + k];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      float dt = p[k].x * d.x + p[k].y * d.y + p[k].z * d.z;
-      if (i0 + k < c.n && dt > best) { best = dt; bv = mk(p[k].x, p[k].y, p[k].z); }
+    for (int k = 0; k < 8; k += 2) {
+#if defined(__HIPCC__)
+      const Pk2 X = {xs[k], xs[k + 1]}, Y = {ys[k], ys[k + 1]}, Z = {zs[k], zs[k + 1]};
+      const Pk2 dt = (X * d.x + Y * d.y) + Z * d.z;
+      const float dt0 = dt.x, dt1 = dt.y;
+#else
+      const float dt0 = xs[k] * d.x + ys[k] * d.y + zs[k] * d.z, dt1 = xs[k + 1] * d.x + ys[k + 1] * d.y + zs[k + 1] * d.z;
+#endif
+      if (dt0 > best) { best = dt0; bv = mk(xs[k], ys[k], zs[k]); }
+      if (dt1 > best) { best = dt1; bv = mk(xs[k + 1], ys[k + 1], zs[k + 1]); }
     }
   }
-  if (!(best > -INFINITY) && c.n > 0) { const F4 p = c.v[0]; bv = mk(p.x, p.y, p.z); }  // all-NaN dots: index 0, like the scan
+  if (!(best > -INFINITY) && c.n > 0) bv = mk(c.vb[0], c.vb[8], c.vb[16]);  // all-NaN dots: index 0, like the scan
   return bv;
 }
 // vertex i of a hull, the same value in every lane of the group
@@ -224,8 +261,8 @@ TOHC_DEV V3 cvxVertex(const Cvx<G> &c, int i) {
 }
 template <>
 TOHC_DEV V3 cvxVertex<1>(const Cvx<1> &c, int i) {
-  const F4 p = c.v[i];
-  return mk(p.x, p.y, p.z);
+  const float *b = c.vb + (i >> 3) * TOHC_VBLOCK + (i & 7);
+  return mk(b[0], b[8], b[16]);
 }
 
 // localGetSupportVertexWithoutMarginNonVirtual for box / hull [cvx:120-296]
@@ -285,13 +322,14 @@ TOHC_DEV float plainReach(const Cvx<1> &c, V3 d, bool withRadius) {
   if (c.kind == KIND_BOX) return fmaf(fabsf(d.x), c.dims.x, fmaf(fabsf(d.y), c.dims.y, fabsf(d.z) * c.dims.z));
   if (c.kind == KIND_CYLZ) return fmaf(c.dims.x, sqrtf(fmaf(d.x, d.x, d.y * d.y)), fabsf(d.z) * c.dims.z);
   float best = -INFINITY;
-  const int last = c.n - 1;
   for (int i0 = 0; i0 < c.n; i0 += 8) {
-    F4 p[8];
+    const F4 *b = reinterpret_cast<const F4 *>(c.vb + 3 * i0);
+    const F4 xa = b[0], xb = b[1], ya = b[2], yb = b[3], za = b[4], zb = b[5];
+    const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+    const float ys[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+    const float zs[8] = {za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) p[k] = c.v[min(i0 + k, last)];   // past the end: the last vertex again
-#pragma unroll
-    for (int k = 0; k < 8; ++k) best = fmaxf(best, fmaf(p[k].x, d.x, fmaf(p[k].y, d.y, p[k].z * d.z)));
+    for (int k = 0; k < 8; ++k) best = fmaxf(best, fmaf(xs[k], d.x, fmaf(ys[k], d.y, zs[k] * d.z)));
   }
   return best;
 }
