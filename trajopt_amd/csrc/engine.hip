@@ -99,6 +99,8 @@ struct tohc_engine {
   double base_T[7], rot_axis[3];
   DBuf<int> d_parent, d_jtype, d_dof, d_dof_col, d_link_dyn, d_obj_jaclink, d_link_obj, d_chain_off, d_chain;
   std::vector<int> h_chain_off, h_chain;
+  DBuf<int4> d_child_jac;          // k_finish's flattened Jacobian tables (DevRobot)
+  DBuf<JacJoint> d_jac_joint;
   bool shared_columns = false;
   DBuf<double> d_T_origin, d_axis, d_mult, d_offs, d_q_robot;
   // dynamic maps: robot mode and all-objects ("poses") mode
@@ -732,6 +734,30 @@ int tohc_upload_robot(tohc_engine *e, int n_links, const int32_t *parent, const 
       }
   }
   hipStream_t s = e->stream;
+  {
+    std::vector<JacJoint> jj;
+    std::vector<int> j0(n_links), j1(n_links);
+    for (int i = 0; i < n_links; ++i) {
+      j0[i] = (int)jj.size();
+      for (int c = e->h_chain_off[i]; c < e->h_chain_off[i + 1]; ++c) {
+        const int j = e->h_chain[c], k = e->h_dof_col[j];
+        if (jtype[j] == TOHC_J_FIXED || k < 0 || k >= n_joint_inds) continue;
+        JacJoint r;
+        memset(&r, 0, sizeof r);
+        r.link = j; r.col = k; r.revolute = jtype[j] == TOHC_J_REVOLUTE ? 1 : 0; r.mult = mult[j];
+        jj.push_back(r);
+      }
+      j1[i] = (int)jj.size();
+    }
+    std::vector<int4> cj(e->n_children);
+    for (int c = 0; c < e->n_children; ++c) {
+      const int l = e->h_obj_jaclink[e->h_child_obj[c]];
+      cj[c] = make_int4(l, l >= 0 ? j0[l] : 0, l >= 0 ? j1[l] : 0, 0);
+    }
+    if (jj.empty()) { JacJoint r; memset(&r, 0, sizeof r); jj.push_back(r); }
+    HIPCHK(upload(e->d_jac_joint, jj, s)); HIPCHK(upload(e->d_child_jac, cj, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
   HIPCHK(upload(e->d_parent, e->h_parent, s)); HIPCHK(upload(e->d_jtype, e->h_jtype, s)); HIPCHK(upload(e->d_dof, e->h_dof, s));
   HIPCHK(upload(e->d_dof_col, e->h_dof_col, s)); HIPCHK(upload(e->d_link_dyn, e->h_link_dyn, s)); HIPCHK(upload(e->d_obj_jaclink, e->h_obj_jaclink, s));
   HIPCHK(upload(e->d_link_obj, e->h_link_obj, s)); HIPCHK(upload(e->d_chain_off, e->h_chain_off, s)); HIPCHK(upload(e->d_chain, e->h_chain, s));
@@ -812,6 +838,7 @@ static DevRobot devRobot(tohc_engine *e) {
   r.parent = e->d_parent.p; r.jtype = e->d_jtype.p; r.dof = e->d_dof.p; r.dof_col = e->d_dof_col.p; r.link_dyn = e->d_link_dyn.p;
   r.T_origin = e->d_T_origin.p; r.axis = e->d_axis.p; r.mult = e->d_mult.p; r.offs = e->d_offs.p; r.q_robot = e->d_q_robot.p;
   r.obj_jaclink = e->d_obj_jaclink.p; r.link_obj = e->d_link_obj.p; r.chain_off = e->d_chain_off.p; r.chain = e->d_chain.p;
+  r.child_jac = e->d_child_jac.p; r.jac_joint = e->d_jac_joint.p;
   r.fast_jac = (!e->shared_columns && e->K <= TOHC_FAST_JAC_MAXK) ? 1 : 0;
   memcpy(r.base_T, e->base_T, sizeof r.base_T);
   memcpy(r.rot_axis, e->rot_axis, sizeof r.rot_axis);

@@ -66,6 +66,10 @@ struct DynMap {          // which objects / children move per set (robot links, 
   int n_cl, n_cl_pad;
 };
 #define TOHC_FAST_JAC_MAXK 64
+// k_finish's tables, flattened so that a contact reaches its joints' poses in two loads after its pair record:
+// child -> (link whose chain gives the Jacobian, its joints' range) and, per link, the joints of its chain that move an
+// optimisation column (fixed joints and joints outside the problem's columns left out)
+struct JacJoint { int link, col, revolute, pad; double mult, pad2; };
 struct DevRobot {
   int n_links, K, n_joint_inds, affine;
   int fast_jac;   // 1: no chain has two joints on one column and K <= TOHC_FAST_JAC_MAXK (k_finish's lane-per-joint epilogue applies)
@@ -73,6 +77,8 @@ struct DevRobot {
   const int *chain_off, *chain;                          // ancestors of each link, root first, the link itself last
   const double *T_origin, *axis, *mult, *offs, *q_robot;
   const int *obj_jaclink;                                // [n_objects] link whose chain gives the Jacobian, or -1
+  const int4 *child_jac;                                 // [n_children] (that link, first, one past the last of its JacJoint records, 0)
+  const JacJoint *jac_joint;
   double base_T[7];
   double rot_axis[3];
 };
@@ -1447,26 +1453,24 @@ __device__ __forceinline__ double linearizeAt(const NarrowArgs &a, int set, int 
 // linearizeAt's: with at most one joint per column (DevRobot.fast_jac) a column's J is 0 + mult*col, exactly.
 // row: [2][K] doubles of the group (A's then B's contributions).
 template <int G>
-__device__ __forceinline__ void jacRow(const DevRobot &rb, const double *linkQT, const double *linkZ, int link, D3 n, D3 p, double *row) {
+__device__ __forceinline__ void jacRow(const DevRobot &rb, const double *linkQT, const double *linkZ, int4 jl, D3 n, D3 p, double *row) {
   const int gl = Grp<G>::lane();
-  const int c0 = rb.chain_off[link], c1 = rb.chain_off[link + 1];
-  for (int c = c0 + gl; c < c1; c += G) {
-    const int i = rb.chain[c];
-    const int k = rb.dof_col[i];
-    if (rb.jtype[i] == TOHC_J_FIXED || k < 0 || k >= rb.n_joint_inds) continue;
-    const double *tq = linkQT + 7 * i, *zq = linkZ + 3 * i;
+  for (int c = jl.y + gl; c < jl.z; c += G) {
+    const JacJoint jj = rb.jac_joint[c];
+    const double *tq = linkQT + 7 * jj.link, *zq = linkZ + 3 * jj.link;
     const D3 z = mkd(zq[0], zq[1], zq[2]);   // = qrot(link pose, axis), bit for bit: k_fk does that product
-    D3 col = rb.jtype[i] == TOHC_J_REVOLUTE ? cross(z, p - mkd(tq[4], tq[5], tq[6])) : z;
+    D3 col = jj.revolute ? cross(z, p - mkd(tq[4], tq[5], tq[6])) : z;
     D3 J = mkd(0, 0, 0);
-    J.x += rb.mult[i] * col.x; J.y += rb.mult[i] * col.y; J.z += rb.mult[i] * col.z;
-    row[k] = n.x * J.x + n.y * J.y + n.z * J.z;
+    J.x += jj.mult * col.x; J.y += jj.mult * col.y; J.z += jj.mult * col.z;
+    row[jj.col] = n.x * J.x + n.y * J.y + n.z * J.z;
   }
 }
 template <int G>
-__device__ __forceinline__ double linearizeFast(const NarrowArgs &a, int set, int la, int lb, D3 n, D3 ptA, D3 ptB, double dist, double *gradOut,
+__device__ __forceinline__ double linearizeFast(const NarrowArgs &a, int set, int4 ja, int4 jb, D3 n, D3 ptA, D3 ptB, double dist, double *gradOut,
                                                 double *row) {
   const DevRobot &rb = a.rb;
   const int gl = Grp<G>::lane();
+  const int la = ja.x, lb = jb.x;
   const double *linkQT = a.linkQT + (size_t)set * rb.n_links * 7;
   const double *linkZ = a.linkZ + (size_t)set * rb.n_links * 3;
   const double *q = a.dofs + (size_t)set * rb.K;
@@ -1480,8 +1484,8 @@ __device__ __forceinline__ double linearizeFast(const NarrowArgs &a, int set, in
     rowA[k] = va; rowB[k] = vb;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the group's lanes share one wavefront: LDS ops are in order
-  if (la >= 0) jacRow<G>(rb, linkQT, linkZ, la, n, ptA, rowA);
-  if (lb >= 0) jacRow<G>(rb, linkQT, linkZ, lb, n, ptB, rowB);
+  if (la >= 0) jacRow<G>(rb, linkQT, linkZ, ja, n, ptA, rowA);
+  if (lb >= 0) jacRow<G>(rb, linkQT, linkZ, jb, n, ptB, rowB);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   for (int k = gl; k < rb.K; k += G) {
     double g = 0;
@@ -1523,8 +1527,17 @@ __global__ void __launch_bounds__(256, TOHC_FINISH_WAVES) k_finish(NarrowArgs a)
     }
     const HitRec h = a.hits[qlocate(pre, a.cp.seg_cap, hIdx)];
     const PairRec pr = a.pairs[h.pair];
+    // both children's descriptors and Jacobian entries in one round of loads
+    const ChildDesc dq = a.sc.child_desc[pr.q];
+    const ChildDesc *dxp = a.sc.child_desc + pr.x;
+    const bool wantJ = a.cp.want_jac && a.linkQT;
+    const int4 none = make_int4(-1, 0, 0, 0);
+    const int4 jq = wantJ ? a.rb.child_jac[pr.q] : none, jx = wantJ ? a.rb.child_jac[pr.x] : none;
     PairIds c;
-    pairIds(a, pr, c);
+    castSets(a.cp, pr.set, c.set0, c.set1);
+    c.Q = dq.obj; c.qc = dq.idx; c.X = dxp->obj; c.xc = dxp->idx;
+    c.xIsA = dxp->compound != 0;
+    int4 jA = c.xIsA ? jx : jq, jB = c.xIsA ? jq : jx;
     V3 nrm = mk(h.n[0], h.n[1], h.n[2]);
     V3 ptB = mk(h.pB[0], h.pB[1], h.pB[2]);
     V3 ptA = ptB + nrm * h.distance;
@@ -1536,7 +1549,7 @@ __global__ void __launch_bounds__(256, TOHC_FINISH_WAVES) k_finish(NarrowArgs a)
     if (a.cp.cast) {
       const bool castFirst = !c.xIsA;
       Cvx<G> cq;
-      loadShape<G>(a.sc, pr.q, cq);
+      cvxLoad<G>(cq, dq.kind, mk(dq.dims[0], dq.dims[1], dq.dims[2]), a.sc.vx, a.sc.vy, a.sc.vz, a.sc.v4, dq.voff, dq.vcnt, a.sc.v8, dq.voff8);
       Xf tf0 = childXf(a, a.dynXf0, c.set0, pr.q);
       Xf tq1 = childXf(a, a.dynXf1, c.set1, pr.q);
       Xf t01 = xfInverseTimes(tf0, tq1);
@@ -1548,21 +1561,22 @@ __global__ void __launch_bounds__(256, TOHC_FINISH_WAVES) k_finish(NarrowArgs a)
         nrm = nrm * -1.0f;
         int ti = idA; idA = idB; idB = ti;
         ti = chA; chA = chB; chB = ti;
+        const int4 tj = jA; jA = jB; jB = tj;
       }
       cctype = co.cctype;
       time = co.time;
       if (co.between) { ptB = co.ptB; ptB1 = co.ptB1; }
     }
     double c0 = 0, c1 = 0;
-    if (a.cp.want_jac && a.linkQT) {
-      const int la = a.rb.obj_jaclink[idA], lb = a.rb.obj_jaclink[idB];
+    if (wantJ) {
+      const int la = jA.x, lb = jB.x;
       D3 n = mkd(nrm.x, nrm.y, nrm.z), pA = mkd(ptA.x, ptA.y, ptA.z), pB = mkd(ptB.x, ptB.y, ptB.z), pB1 = mkd(ptB1.x, ptB1.y, ptB1.z);
       double *g = a.grads + (size_t)slot * 2 * a.rb.K;
-      c0 = fast ? linearizeFast<G>(a, c.set0, la, lb, n, pA, pB, (double)h.distance, g, row)
+      c0 = fast ? linearizeFast<G>(a, c.set0, jA, jB, n, pA, pB, (double)h.distance, g, row)
                 : linearizeAt<G>(a, c.set0, la, lb, n, pA, pB, (double)h.distance, g);
       if (a.cp.cast) {
         const D3 pBc = (cctype == TOHC_CC_BETWEEN) ? pB1 : pB;
-        c1 = fast ? linearizeFast<G>(a, c.set1, la, lb, n, pA, pBc, (double)h.distance, g + a.rb.K, row)
+        c1 = fast ? linearizeFast<G>(a, c.set1, jA, jB, n, pA, pBc, (double)h.distance, g + a.rb.K, row)
                   : linearizeAt<G>(a, c.set1, la, lb, n, pA, pBc, (double)h.distance, g + a.rb.K);
       } else {
         for (int k = gl; k < a.rb.K; k += G) g[a.rb.K + k] = 0;
