@@ -438,6 +438,38 @@ __device__ __forceinline__ void loadSide(const NarrowArgs &a, int child, const C
   }
 }
 
+// The same for a child that is the same in every lane (k_broadphase's query): descriptor and poses through scalar loads
+__device__ __forceinline__ Xf ldXfU(const float *p) {
+  const TOHC_CONST_AS float *u = uniformPtr(p);
+  Xf t;
+  t.b.r[0] = mk(u[0], u[1], u[2]);
+  t.b.r[1] = mk(u[3], u[4], u[5]);
+  t.b.r[2] = mk(u[6], u[7], u[8]);
+  t.o = mk(u[9], u[10], u[11]);
+  return t;
+}
+__device__ __forceinline__ Aabb ldAabbU(const float *p) {
+  const TOHC_CONST_AS float *u = uniformPtr(p);
+  Aabb b;
+  b.lo = mk(u[0], u[1], u[2]);
+  b.hi = mk(u[3], u[4], u[5]);
+  return b;
+}
+__device__ __forceinline__ void loadSideU(const NarrowArgs &a, int child, int set0, int set1, bool cast, Cvx<1> &c, Xf &t0, int slot) {
+  const TOHC_CONST_AS ChildDesc *cd = uniformPtr(a.sc.child_desc + child);
+  c.kind = cd->kind;
+  c.cast = 0;
+  c.n = cd->vcnt;
+  c.dims = mk(cd->dims[0], cd->dims[1], cd->dims[2]);
+  c.vb = a.sc.v8 + (size_t)cd->voff8 * TOHC_VBLOCK;
+  t0 = slot >= 0 ? ldXfU(a.dynXf0 + ((size_t)set0 * a.dm.n_dyn_children + slot) * 12) : ldXfU(a.sc.stat_xf + 12 * child);
+  if (cast) {
+    Xf t1 = slot >= 0 ? ldXfU(a.dynXf1 + ((size_t)set1 * a.dm.n_dyn_children + slot) * 12) : ldXfU(a.sc.stat_xf + 12 * child);
+    c.cast = 1;
+    c.t01 = xfInverseTimes(t0, t1);
+  }
+}
+
 // -----------------------------------------------------------------------------------------------------------------
 // k_broadphase: ONE WAVEFRONT per (unit, query child).  Filters follow CollisionCollector::needsCollision
 // (bullet_collision_checker.cpp:409-413) and btSingleContactCallback::process (btCollisionWorld.cpp:1129-1137); the
@@ -483,15 +515,16 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
   const int lane = threadIdx.x;
   const int qi = blockIdx.x % ca.nQ;
   const int cs = cp.unit_base + blockIdx.x / ca.nQ;
-  const int4 qinfo = reinterpret_cast<const int4 *>(ca.qchildren)[qi];   // (child, object, moving slot or -1, 0)
-  const int q = qinfo.x;
-  const int Q = qinfo.y;
+  // everything about the query child is the same in every lane: scalar loads (uniformPtr)
+  const TOHC_CONST_AS int *qinfo = uniformPtr(ca.qchildren + 4 * qi);   // (child, object, moving slot or -1, 0)
+  const int q = qinfo[0];
+  const int Q = qinfo[1];
   const int shard = blockIdx.x % TOHC_NSHARD;
   int set0, set1;
   castSets(cp, cs, set0, set1);
-  const int qs = qinfo.z;
-  Aabb bq = qs >= 0 ? ldAabb(ca.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + qs) * 6) : ldAabb(sc.stat_aabb + 6 * q);
-  if (CAST && qs >= 0) bq = aabbUnion(bq, ldAabb(ca.dynAabb1 + ((size_t)set1 * dm.n_dyn_children + qs) * 6));
+  const int qs = qinfo[2];
+  Aabb bq = qs >= 0 ? ldAabbU(ca.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + qs) * 6) : ldAabbU(sc.stat_aabb + 6 * q);
+  if (CAST && qs >= 0) bq = aabbUnion(bq, ldAabbU(ca.dynAabb1 + ((size_t)set1 * dm.n_dyn_children + qs) * 6));
   const unsigned char *allowedRow = sc.allowed + (size_t)Q * sc.n_objects;
   const float lim = cp.d * 1.01f + 1.0e-4f;  // guard band: the bound and Bullet's result both carry ~1e-6 of rounding
   unsigned int nq = 0, ncand = 0;            // wave-uniform
@@ -499,7 +532,7 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
   // with the scan's instead of starting a chain of their own at the first drain
   Cvx<1> cq;
   Xf tq;
-  if (ca.pretest) loadSide<1>(a, q, sc.child_desc[q], set0, set1, CAST, cq, tq, qs);
+  if (ca.pretest) loadSideU(a, q, set0, set1, CAST, cq, tq, qs);
   // first block of the moving children's boxes, likewise ahead of the scan of the static table
   Aabb bd0;
   bd0.lo = mk(1.f, 1.f, 1.f); bd0.hi = mk(-1.f, -1.f, -1.f);
@@ -547,7 +580,7 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
         const float dl2 = len2(dir);
         if (dl2 > 1.0e-12f) {
           const float dl = sqrtf(dl2);
-          const float eA = reachNV(cq, mulVM(-dir, tq.b));   // how far the query reaches towards the other child
+          const float eA = reachNV<true>(cq, mulVM(-dir, tq.b));   // how far the query reaches towards the other child
           const float mq = cvxMargin<1>(cq);   // a plain sphere is its centre + this much (0 for everything else)
           const float deltaS = dl2 - eA - (rad + mq) * dl;
           if ((deltaS > 0.0f && deltaS > lim * dl) || ca.dbg == 2) {
@@ -1505,7 +1538,7 @@ __device__ __forceinline__ double linearizeFast(const NarrowArgs &a, int set, in
 // (bullet_collision_checker.cpp:894-972), record + gradient rows.
 template <int G>
 #ifndef TOHC_FINISH_WAVES
-#define TOHC_FINISH_WAVES 4
+#define TOHC_FINISH_WAVES 2   // no spills (4: 128 VGPRs, 73 spilled; measured 2: 0.205, 3: 0.26, 4: 0.22, 5: 0.31 ms per launch)
 #endif
 __global__ void __launch_bounds__(256, TOHC_FINISH_WAVES) k_finish(NarrowArgs a) {
   extern __shared__ double s_rows[];   // [256 / G][2][K]: the groups' gradient rows (launch: finishLds)

@@ -317,11 +317,33 @@ TOHC_DEV V3 supWithMarginNV(const Cvx<G> &c, V3 d) {
 // The shape is supNV's: without its margin when plain, the swept hull of both poses (a sphere with its radius) when cast.
 // ---------------------------------------------------------------------------------------------------------------
 #if defined(__HIPCC__)
+// A pointer that is the same in every lane of the wavefront, as one the compiler KNOWS is uniform and read-only: loads
+// through it are scalar loads (SGPR results, the scalar cache), not 64 copies of one value through the vector memory
+// path -- a wave-uniform 16-byte vector load costs that path the same 1 KB of register writes as a gather.  Only for
+// tables written before the kernel started (the scalar cache is not coherent with this kernel's own stores).
+#define TOHC_CONST_AS __attribute__((address_space(4)))
+template <class T>
+TOHC_DEV const TOHC_CONST_AS T *uniformPtr(const T *p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v), hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+  return (const TOHC_CONST_AS T *)(((unsigned long long)hi << 32) | lo);
+}
+// UNIFORM: the shape is the same in every lane (k_broadphase's query child): its vertices come through scalar loads
+template <bool UNIFORM>
 TOHC_DEV float plainReach(const Cvx<1> &c, V3 d, bool withRadius) {
   if (c.kind == KIND_SPHERE) return withRadius ? c.dims.x * sqrtf(len2(d)) : 0.0f;
   if (c.kind == KIND_BOX) return fmaf(fabsf(d.x), c.dims.x, fmaf(fabsf(d.y), c.dims.y, fabsf(d.z) * c.dims.z));
   if (c.kind == KIND_CYLZ) return fmaf(c.dims.x, sqrtf(fmaf(d.x, d.x, d.y * d.y)), fabsf(d.z) * c.dims.z);
   float best = -INFINITY;
+  if (UNIFORM) {
+    const int n = __builtin_amdgcn_readfirstlane(c.n);
+    const TOHC_CONST_AS float *b = uniformPtr(c.vb);
+    for (int i0 = 0; i0 < n; i0 += 8, b += TOHC_VBLOCK) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) best = fmaxf(best, fmaf(b[k], d.x, fmaf(b[8 + k], d.y, b[16 + k] * d.z)));
+    }
+    return best;
+  }
   for (int i0 = 0; i0 < c.n; i0 += 8) {
     const F4 *b = reinterpret_cast<const F4 *>(c.vb + 3 * i0);
     const F4 xa = b[0], xb = b[1], ya = b[2], yb = b[3], za = b[4], zb = b[5];
@@ -333,10 +355,11 @@ TOHC_DEV float plainReach(const Cvx<1> &c, V3 d, bool withRadius) {
   }
   return best;
 }
+template <bool UNIFORM = false>
 TOHC_DEV float reachNV(const Cvx<1> &c, V3 d) {
-  if (!c.cast) return plainReach(c, d, false);
-  const float e0 = plainReach(c, d, true);
-  const float e1 = plainReach(c, mulVM(d, c.t01.b), true) + dot(d, c.t01.o);
+  if (!c.cast) return plainReach<UNIFORM>(c, d, false);
+  const float e0 = plainReach<UNIFORM>(c, d, true);
+  const float e1 = plainReach<UNIFORM>(c, mulVM(d, c.t01.b), true) + dot(d, c.t01.o);
   return fmaxf(e0, e1);
 }
 #endif
