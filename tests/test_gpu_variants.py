@@ -21,7 +21,9 @@ pytestmark = pytest.mark.gpu
 VARIANTS = [{}, {"TOHC_PRETEST": "0"}, {"TOHC_STREAMS": "1"}, {"TOHC_CHUNKS": "2", "TOHC_STREAMS": "4"}, {"TOHC_HOST_SORT": "1"},
             {"TOHC_GJK_GROUP": "16"}, {"TOHC_EPA_BLOCK": "16"}, {"TOHC_GROUP": "64"}, {"TOHC_MERGE_TAIL": "1"},
             {"TOHC_EPA_SMALL": "5,10"},   # EPA's first-attempt pools so small that most runs are repeated on the full pools
-            {"TOHC_DEFER_EXACT": "0"}]    # the exact stage of the pre-test inside k_broadphase instead of in k_exact
+            {"TOHC_DEFER_EXACT": "0"},    # the exact stage of the pre-test inside k_broadphase instead of in k_exact
+            {"TOHC_GJK_SPLIT": "0"},      # every GJK run ends where it started (k_gjk) ...
+            {"TOHC_GJK_SPLIT": "1"}]      # ... or nearly every one goes on in k_gjk_cont (default: after 6 passes)
 
 
 def _world():

@@ -132,6 +132,7 @@ struct tohc_engine {
     DBuf<EpaRec> epaq;
     DBuf<PenRec> penq;
     DBuf<unsigned int> distq;
+    DBuf<GjkCont> contq;
     DBuf<HitRec> hits;
   };
   Lane lane[4];
@@ -215,6 +216,7 @@ struct tohc_engine {
   int unit_broadphase = 1024;   // k_broadphase_unit from this many units on (one wavefront per unit: fewer units leave the chip empty and
                                 // a wavefront per (unit, query child) answers sooner); TOHC_UNIT_BP=n sets it, 0 = never
   unsigned int epa_small_v = TOHC_EPA_SMALL_V, epa_small_f = TOHC_EPA_SMALL_F;   // TOHC_EPA_SMALL=v,f shrinks k_tail_epa's first-attempt pools (tests of the repeat path)
+  int gjk_split = 6;     // TOHC_GJK_SPLIT=n: k_gjk hands runs still going after n passes to k_gjk_cont (0: never; measured on config 4: 0: 2.555 ms per step, 3: 2.58, 5: 2.50, 6: 2.49, 7: 2.52, 8: 2.56)
   int defer_exact = 1;   // TOHC_DEFER_EXACT=0: the exact stage of the pre-test stays inside k_broadphase
   int pretest = 1;   // TOHC_PRETEST=0 turns the separating-axis pre-test off (A/B measurements)
   tohc_engine() { memset(&counters, 0, sizeof counters); }
@@ -321,6 +323,7 @@ int tohc_create(tohc_engine **out, int device) {
   if (g && atoi(g) == 64) e->group = 64;
   if (const char *pt = getenv("TOHC_PRETEST")) e->pretest = atoi(pt) != 0;
   if (const char *pt = getenv("TOHC_DEFER_EXACT")) e->defer_exact = atoi(pt) != 0;
+  if (const char *pt = getenv("TOHC_GJK_SPLIT")) e->gjk_split = std::max(0, atoi(pt));
   if (const char *ns = getenv("TOHC_STREAMS")) e->n_lanes = std::min(std::max(atoi(ns), 1), 4);
   if (const char *nc = getenv("TOHC_CHUNKS")) e->chunks = std::min(std::max(atoi(nc), 1), 4);
   if (hipEventCreateWithFlags(&e->ev_fk, hipEventDisableTiming) != hipSuccess) { tohc_destroy(e); return TOHC_E_HIP; }
@@ -1100,6 +1103,8 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
   HIPCHK(ln.pairs.reserve(qcap)); HIPCHK(ln.epaq.reserve(qcap)); HIPCHK(ln.hits.reserve(qcap));
   HIPCHK(ln.penq.reserve((size_t)(cp.seg_cap / TOHC_PEN_DIV) * TOHC_NSHARD));
   HIPCHK(ln.distq.reserve(qcap));
+  cp.gjk_split = e->gjk_group == 1 ? e->gjk_split : 0;
+  if (cp.gjk_split > 0) HIPCHK(ln.contq.reserve((size_t)(cp.seg_cap / TOHC_CONT_DIV) * TOHC_NSHARD));
   if (e->defer_exact) HIPCHK(ln.cands.reserve(qcap));
 #if defined(TOHC_EPA_PROF)
   if (!e->d_dbg.p) { HIPCHK(e->d_dbg.reserve(160)); HIPCHK(hipMemset(e->d_dbg.p, 0, 160 * sizeof(unsigned long long))); }
@@ -1117,7 +1122,7 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
   a.linkQT = robotMode ? e->d_linkQT.p : nullptr;
   a.linkZ = robotMode ? e->d_linkZ.p : nullptr;
   a.dofs = robotMode ? e->d_dofs.p : nullptr;
-  a.pairs = ln.pairs.p; a.cands = ln.cands.p; a.epaq = ln.epaq.p; a.penq = ln.penq.p; a.distq = ln.distq.p; a.hits = ln.hits.p; a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p; a.rec_base = e->d_rec_base.p + slot;
+  a.pairs = ln.pairs.p; a.cands = ln.cands.p; a.epaq = ln.epaq.p; a.penq = ln.penq.p; a.distq = ln.distq.p; a.contq = ln.contq.p; a.hits = ln.hits.p; a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p; a.rec_base = e->d_rec_base.p + slot;
   a.records = e->d_records.p; a.grads = e->d_grads.p; a.dbg = e->d_dbg.p;
   if (!oh.empty) {
     const size_t blocks = (size_t)cp.n_cast_sets * nQ;
@@ -1165,6 +1170,10 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
     if (e->gjk_group == 1) {  // one lane per pair, one wavefront per block
       if (cp.cast) hipLaunchKernelGGL((k_gjk<1, true, 64>), dim3(TOHC_GJK_GRID), dim3(64), 0, s, a);
       else hipLaunchKernelGGL((k_gjk<1, false, 64>), dim3(TOHC_GJK_GRID), dim3(64), 0, s, a);
+      if (cp.gjk_split > 0) {
+        if (cp.cast) hipLaunchKernelGGL((k_gjk_cont<true>), dim3(TOHC_CONT_GRID), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((k_gjk_cont<false>), dim3(TOHC_CONT_GRID), dim3(64), 0, s, a);
+      }
     } else if (e->gjk_group == 64) {
       if (cp.cast) hipLaunchKernelGGL((k_gjk<64, true, 256>), dim3(gridN), dim3(256), 0, s, a);
       else hipLaunchKernelGGL((k_gjk<64, false, 256>), dim3(gridN), dim3(256), 0, s, a);

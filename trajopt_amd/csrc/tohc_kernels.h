@@ -86,6 +86,16 @@ struct PairRec { int set, q, x, pad; };
 struct EpaRec { int pair; int isValid; float distance; float n[3]; float pB[3]; };
 struct HitRec { int pair; float distance; float n[3]; float pB[3]; };
 struct PenRec { EpaRec e; PenHand h; };   // k_pen -> k_epa
+// a GJK run after a few passes of its loop, everything the next pass reads (k_gjk -> k_gjk_cont): the simplex holds at most
+// three vertices then (a fourth ends the loop), its closest points are up to date
+struct GjkCont {
+  unsigned int pos;   // the pair's place in the pair list
+  int curIter, n, cachedValid;
+  float squaredDistance;
+  float sep[3], lastW[3], cP1[3], cP2[3];
+  float W[3][3], P[3][3], Q[3][3];
+};
+#define TOHC_CONT_DIV 8                    // the k_gjk -> k_gjk_cont queue holds 1/8 of the pair capacity (a full queue: the run stays where it is)
 #ifndef TOHC_EPA_WAVES
 #define TOHC_EPA_WAVES 2
 #endif
@@ -104,7 +114,8 @@ struct CounterShard {
   unsigned int n_epa_sups;    // the same in k_epa (one per EPA iteration, plus EncloseOrigin's)
   unsigned int n_epa_redone;  // EPA runs repeated on the full pools
   unsigned int n_exact;       // pairs k_broadphase's sphere stage leaves for k_exact (NarrowArgs.cands)
-  unsigned int pad[22];
+  unsigned int n_cont;        // GJK runs k_gjk hands to k_gjk_cont (NarrowArgs.contq)
+  unsigned int pad[21];
 };
 struct Counters {
   CounterShard sh[TOHC_NSHARD];
@@ -128,6 +139,7 @@ struct CallParams {
   int dbg_max_iter;          // diagnostics only: 1000 = the reference's gGjkMaxIter
   int ordered_pairs;         // AllVsAll: a query child meets only the children of objects with a higher number
   unsigned int epa_small_v, epa_small_f;   // k_tail_epa's first-attempt pools (<= TOHC_EPA_SMALL_V / _F; smaller only in tests)
+  int gjk_split;             // k_gjk (a lane per pair) hands a run to k_gjk_cont after this many passes of the loop; 0 = never
 };
 
 __host__ __device__ __forceinline__ Xf ldXf(const float *p) {
@@ -394,6 +406,7 @@ struct NarrowArgs {
   PairRec *cands;         // k_broadphase -> k_exact: what the sphere stage of the pre-test passes (pad = the other child's slot + 1 if it moves)
   EpaRec *epaq;
   PenRec *penq;
+  GjkCont *contq;
   unsigned int *distq;    // positions in epaq of the pairs for the Distance fall-back (k_tail_pen -> the extra blocks of k_tail_epa)
   HitRec *hits;
   Counters *cnt;
@@ -1080,6 +1093,60 @@ __device__ __forceinline__ void pushIfContact(const NarrowArgs &a, unsigned int 
   }
 }
 
+// the end of a GJK run: the pair goes to the penetration queue (EPA) and / or becomes a hit
+template <int G>
+__device__ __forceinline__ void gjkDone(const NarrowArgs &a, unsigned int pos, GjkRun<G> &g, const Cvx<G> &cA, const Cvx<G> &cB, float md2p) {
+  GjkState st;
+  g.finish(st, cvxMargin<G>(cA), cvxMargin<G>(cB));
+  const int shard = blockIdx.x % TOHC_NSHARD;
+  unsigned int slot = 0;
+  bool writeE = st.needEpa;
+  if (G == 1) slot = waveSlot(&a.cnt->sh[shard].n_epa, st.needEpa);
+  else if (st.needEpa && Grp<G>::lane() == 0) slot = atomicAdd(&a.cnt->sh[shard].n_epa, 1u);
+  else writeE = false;
+  if (writeE) {
+    if (slot < a.cp.seg_cap) {
+      EpaRec e;
+      e.pair = (int)pos;
+      e.isValid = st.isValid;
+      e.distance = st.distance;
+      e.n[0] = st.normalInB.x; e.n[1] = st.normalInB.y; e.n[2] = st.normalInB.z;
+      e.pB[0] = st.pointOnB.x; e.pB[1] = st.pointOnB.y; e.pB[2] = st.pointOnB.z;
+      a.epaq[(size_t)shard * a.cp.seg_cap + slot] = e;
+    } else {
+      a.cnt->overflow = 1;
+    }
+  }
+  // (every lane that finished in this step takes part in the vote inside; pairs on their way to EPA are no contact yet)
+  GjkState sh = st;
+  if (st.needEpa) sh.isValid = false;
+  pushIfContact<G>(a, pos, sh, md2p);
+}
+template <int G>
+__device__ __forceinline__ void gjkSave(GjkCont &o, unsigned int pos, const GjkRun<G> &g) {
+  GjkCont r;
+  r.pos = pos; r.curIter = g.curIter; r.n = g.sx.n; r.cachedValid = g.sx.cachedValid ? 1 : 0;
+  r.squaredDistance = g.squaredDistance;
+  st3(r.sep, g.sep); st3(r.lastW, g.sx.lastW); st3(r.cP1, g.sx.cP1); st3(r.cP2, g.sx.cP2);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { st3(r.W[k], g.sx.W[k]); st3(r.P[k], g.sx.P[k]); st3(r.Q[k], g.sx.Q[k]); }
+  o = r;
+}
+// (after g.init with the pair's poses)
+__device__ __forceinline__ void gjkRestore(GjkRun<1> &g, const GjkCont &r) {
+  g.curIter = r.curIter; g.squaredDistance = r.squaredDistance;
+  g.sep = mk(r.sep[0], r.sep[1], r.sep[2]);
+  g.sx.n = r.n; g.sx.cachedValid = r.cachedValid != 0; g.sx.needsUpdate = false;
+  g.sx.lastW = mk(r.lastW[0], r.lastW[1], r.lastW[2]);
+  g.sx.cP1 = mk(r.cP1[0], r.cP1[1], r.cP1[2]); g.sx.cP2 = mk(r.cP2[0], r.cP2[1], r.cP2[2]);
+  g.sx.cV = g.sep;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    g.sx.W[k] = mk(r.W[k][0], r.W[k][1], r.W[k][2]); g.sx.P[k] = mk(r.P[k][0], r.P[k][1], r.P[k][2]); g.sx.Q[k] = mk(r.Q[k][0], r.Q[k][1], r.Q[k][2]);
+  }
+  g.sx.W[3] = g.sx.P[3] = g.sx.Q[3] = mk(0, 0, 0);
+}
+
 // Pairs are handed out in runs of TOHC_RUN consecutive list entries per group: the broadphase writes the survivors of
 // one (unit, query child) block contiguously, so within a run the query side (shape registers, pose, swept transform)
 // is usually unchanged and only the other side is reloaded.
@@ -1150,33 +1217,59 @@ __global__ void __launch_bounds__(BLOCK, TOHC_GJK_WAVES) k_gjk(NarrowArgs a) {
     // that it takes no register of its own across the loop (with zero margins it is the launch-wide constant)
     const float md2p = pairMaxDist2<G>(cA, cB, a.cp.breaking);
     if (g.step(cA, cB, tA, tB, md2p, maxIter)) {
-      GjkState st;
-      g.finish(st, cvxMargin<G>(cA), cvxMargin<G>(cB));
+      gjkDone<G>(a, pos, g, cA, cB, md2p);
       active = false;
+    } else if (G == 1 && a.cp.gjk_split > 0 && g.curIter == a.cp.gjk_split) {
+      // A wavefront lasts as long as its longest run, and the runs are uneven (most end within four passes, one in four
+      // takes up to twice as many): the long ones go on in k_gjk_cont, packed into full wavefronts again.
       const int shard = blockIdx.x % TOHC_NSHARD;
-      unsigned int slot = 0;
-      bool writeE = st.needEpa;
-      if (G == 1) slot = waveSlot(&a.cnt->sh[shard].n_epa, st.needEpa);
-      else if (st.needEpa && Grp<G>::lane() == 0) slot = atomicAdd(&a.cnt->sh[shard].n_epa, 1u);
-      else writeE = false;
-      if (writeE) {
-        if (slot < a.cp.seg_cap) {
-          EpaRec e;
-          e.pair = (int)pos;
-          e.isValid = st.isValid;
-          e.distance = st.distance;
-          e.n[0] = st.normalInB.x; e.n[1] = st.normalInB.y; e.n[2] = st.normalInB.z;
-          e.pB[0] = st.pointOnB.x; e.pB[1] = st.pointOnB.y; e.pB[2] = st.pointOnB.z;
-          a.epaq[(size_t)shard * a.cp.seg_cap + slot] = e;
-        } else {
-          a.cnt->overflow = 1;
-        }
+      const unsigned int cap = a.cp.seg_cap / TOHC_CONT_DIV;
+      const unsigned int slot = waveSlot(&a.cnt->sh[shard].n_cont, true);
+      if (slot < cap) {   // (a full queue: the run simply stays)
+        gjkSave(a.contq[(size_t)shard * cap + slot], pos, g);
+        active = false;
       }
-      // (every lane that finished in this step takes part in the vote inside; pairs on their way to EPA are no contact yet)
-      GjkState sh = st;
-      if (st.needEpa) sh.isValid = false;
-      pushIfContact<G>(a, pos, sh, md2p);
     }
+  }
+  waveAdd(&a.cnt->sh[blockIdx.x % TOHC_NSHARD].n_gjk_steps, steps);
+}
+
+// k_gjk_cont: the GJK runs k_gjk left unfinished, ONE LANE per run, from where they stopped (same operands, same state,
+// same loop: the results are k_gjk's own).
+#define TOHC_CONT_GRID 2048
+template <bool CAST>
+__global__ void __launch_bounds__(64, TOHC_GJK_WAVES) k_gjk_cont(NarrowArgs a) {
+  const unsigned int cap = a.cp.seg_cap / TOHC_CONT_DIV;
+  QPrefix pre;
+  qprefix(&a.cnt->sh[0].n_cont, cap, pre);
+  const unsigned int n = pre.start[TOHC_NSHARD];
+  const int maxIter = a.cp.dbg_max_iter;
+  unsigned int steps = 0;
+  for (unsigned int i = blockIdx.x * 64u + threadIdx.x; i < n; i += gridDim.x * 64u) {
+    const GjkCont rec = a.contq[qlocate(pre, cap, i)];
+    const PairRec pr = a.pairs[rec.pos];
+    const ChildDesc dx = a.sc.child_desc[pr.x];
+    int set0, set1;
+    castSets(a.cp, pr.set, set0, set1);
+    const bool xIsA = dx.compound != 0;
+    Cvx<1> cA, cB;
+    Xf tA, tB;
+    if (xIsA) {
+      loadSide<1>(a, pr.x, dx, set0, set1, false, cA, tA);
+      loadSide<1>(a, pr.q, a.sc.child_desc[pr.q], set0, set1, CAST, cB, tB);
+    } else {
+      loadSide<1>(a, pr.x, dx, set0, set1, false, cB, tB);
+      loadSide<1>(a, pr.q, a.sc.child_desc[pr.q], set0, set1, CAST, cA, tA);
+    }
+    GjkRun<1> g;
+    g.init(tA, tB);
+    gjkRestore(g, rec);
+    const float md2p = pairMaxDist2<1>(cA, cB, a.cp.breaking);
+    for (;;) {
+      ++steps;
+      if (g.step(cA, cB, tA, tB, md2p, maxIter)) break;
+    }
+    gjkDone<1>(a, rec.pos, g, cA, cB, md2p);
   }
   waveAdd(&a.cnt->sh[blockIdx.x % TOHC_NSHARD].n_gjk_steps, steps);
 }
