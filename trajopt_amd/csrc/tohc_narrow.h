@@ -31,6 +31,12 @@ struct Grp {
 #if defined(__HIPCC__)
   static TOHC_DEV int lane() { return (int)(threadIdx.x & (G - 1)); }
   static TOHC_DEV float bcast(float v, int src) { return __shfl(v, src, G); }
+  // the same with the source lane known at compile time: inside a quad that is ONE DPP move, no trip through the LDS crossbar
+  template <int SRC>
+  static TOHC_DEV float bcastC(float v) {
+    if constexpr (G == 4) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), SRC * 0x55, 0xf, 0xf, false));
+    else return __shfl(v, SRC, G);
+  }
   // lexicographic (max value, min index) all-reduce.  Inside a 16-lane DPP row the butterfly is four single VALU
   // DPP moves (quad_perm xor-1, quad_perm xor-2, row_half_mirror, row_mirror): no LDS crossbar round trips.
   static TOHC_DEV void combine(float &v, int &i, float ov, int oi) {
@@ -204,6 +210,9 @@ TOHC_DEV V3 hullMaxDot(const Cvx<G> &c, V3 d) {
 #pragma unroll
   for (int s = 0; s < Cvx<G>::VPL; ++s) {
     int i = s * G + gl;
+#if defined(__HIPCC__)
+    if (__builtin_amdgcn_ballot_w64(i < c.n) == 0) break;   // no hull of this wavefront has a vertex in this slot or a later one
+#endif
     float dt = c.x[s] * d.x + c.y[s] * d.y + c.z[s] * d.z;
     if (i < c.n && dt > best) { best = dt; bi = i; }
   }
@@ -1675,11 +1684,26 @@ TOHC_DEV void avgStep(AvgAcc &a, V3 pt, V3 nl) {
 }
 // hull vertices in index order; the register slots are indexed by compile-time constants only (a dynamic slot index
 // sends the whole vertex array through scratch memory: 80 bytes per LANE and hit, 650 MB per launch of k_finish)
+#if defined(__HIPCC__)
+template <int G, int SRC>
+struct AvgSrc {   // vertices base + SRC .. base + G - 1 of one register slot, source lanes as compile-time constants
+  static TOHC_DEV void run(float x, float y, float z, int base, int n, V3 nl, AvgAcc &a) {
+    if (base + SRC < n) avgStep(a, mk(Grp<G>::template bcastC<SRC>(x), Grp<G>::template bcastC<SRC>(y), Grp<G>::template bcastC<SRC>(z)), nl);
+    if constexpr (SRC + 1 < G) AvgSrc<G, SRC + 1>::run(x, y, z, base, n, nl, a);
+  }
+};
+#endif
 template <int G>
 TOHC_DEV void avgHull(const Cvx<G> &c, V3 nl, AvgAcc &a) {
 #pragma unroll
   for (int s = 0; s < Cvx<G>::VPL; ++s) {
     if (s * G >= c.n) break;
+#if defined(__HIPCC__)
+    if constexpr (G == 4) {
+      AvgSrc<G, 0>::run(c.x[s], c.y[s], c.z[s], s * G, c.n, nl, a);
+      continue;
+    }
+#endif
     const int lim = c.n - s * G < G ? c.n - s * G : G;
     for (int src = 0; src < lim; ++src) avgStep(a, mk(Grp<G>::bcast(c.x[s], src), Grp<G>::bcast(c.y[s], src), Grp<G>::bcast(c.z[s], src)), nl);
   }
@@ -1724,9 +1748,19 @@ TOHC_DEV void castClassify(const Cvx<G> &cq, const Xf &tf0, const Xf &tw1, V3 nW
   V3 nl1 = mulVM(nFromCast, tw1.b);
   V3 pl0, pl1;
   float ls0, ls1;
-  averageSupport<G>(cq, nl0, ls0, pl0);
+  if constexpr (G >= 2) {
+    // every lane of a group would do the same vertex-by-vertex scan twice (the average is order-dependent, so it stays a
+    // scan): the lower half of the group takes the first pose's direction, the upper half the second's, in ONE scan
+    const bool second = (Grp<G>::lane() & (G / 2)) != 0;
+    V3 pl;
+    averageSupport<G>(cq, second ? nl1 : nl0, ls0, pl);
+    pl0 = mk(Grp<G>::bcast(pl.x, 0), Grp<G>::bcast(pl.y, 0), Grp<G>::bcast(pl.z, 0));
+    pl1 = mk(Grp<G>::bcast(pl.x, G / 2), Grp<G>::bcast(pl.y, G / 2), Grp<G>::bcast(pl.z, G / 2));
+  } else {
+    averageSupport<G>(cq, nl0, ls0, pl0);
+    averageSupport<G>(cq, nl1, ls1, pl1);
+  }
   V3 pw0 = xfApply(tf0, pl0);
-  averageSupport<G>(cq, nl1, ls1, pl1);
   V3 pw1 = xfApply(tw1, pl1);
   float sup0 = dot(nFromCast, pw0);
   float sup1 = dot(nFromCast, pw1);
