@@ -703,7 +703,9 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
 // Same direction (query origin - the other child's bounding-sphere centre, read from the same record), same support
 // points, same test as the stage inside the broadphase kernels: the pair list k_gjk gets holds the same pairs.
 // -----------------------------------------------------------------------------------------------------------------
+#ifndef TOHC_EXACT_GRID
 #define TOHC_EXACT_GRID 4096
+#endif
 template <bool CAST>
 __global__ void __launch_bounds__(64) k_exact(CullArgs ca) {
   const NarrowArgs &a = ca.a;
@@ -1236,7 +1238,9 @@ __global__ void __launch_bounds__(BLOCK, TOHC_GJK_WAVES) k_gjk(NarrowArgs a) {
 
 // k_gjk_cont: the GJK runs k_gjk left unfinished, ONE LANE per run, from where they stopped (same operands, same state,
 // same loop: the results are k_gjk's own).
+#ifndef TOHC_CONT_GRID
 #define TOHC_CONT_GRID 2048
+#endif
 template <bool CAST>
 __global__ void __launch_bounds__(64, TOHC_GJK_WAVES) k_gjk_cont(NarrowArgs a) {
   const unsigned int cap = a.cp.seg_cap / TOHC_CONT_DIV;
