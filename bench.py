@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak
-CATS = {"k_broadphase": "broadphase", "k_gjk": "gjk", "k_pen": "epa", "k_epa": "epa", "k_tail_pen": "epa", "k_tail_epa": "epa",
+CATS = {"k_broadphase": "broadphase", "k_exact": "broadphase", "k_gjk": "gjk", "k_gjk_cont": "gjk", "k_pen": "epa", "k_epa": "epa", "k_tail_pen": "epa", "k_tail_epa": "epa",
         "k_finish": "finish", "k_tail_finish": "finish"}
 
 
