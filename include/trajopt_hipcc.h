@@ -247,7 +247,9 @@ int tohc_forward_kinematics(tohc_engine *e, const double *dofs, int n_cfg, doubl
 
 int tohc_get_counters(const tohc_engine *e, tohc_counters *out);
 
-/* capacity knobs (defaults sized for SURVEY config 4 on one MI355X) */
+/* capacity knobs (defaults sized for SURVEY config 4 on one MI355X).  max_pairs bounds, per enqueue, the pairs handed to
+ * the iterative solver AND the pre-test's intermediate list (pairs whose bounding-sphere test could not separate them,
+ * about twice as many); max_records the contact records of one slab.  Overflow = TOHC_E_CAPACITY, nothing is truncated. */
 int tohc_set_capacity(tohc_engine *e, int64_t max_pairs, int64_t max_records);
 
 /* replaces BulletCollisionChecker::AllVsAll                   src/trajopt/bullet_collision_checker.cpp:463-498, 415-422
