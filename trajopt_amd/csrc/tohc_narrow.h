@@ -1238,13 +1238,20 @@ struct Epa {
   //   makeHorizon(): makes all the new faces at once, one lane per face, and binds the fan.
   // A failure the reference meets half way (degenerate / non-convex new face, out of faces, a face reached twice) ends
   // its iteration with what it had before (E_INVALIDHULL: the result is the previous best face), and it does here.
+  // The two entries at the top of the stack live in registers: `top` is the entry being worked on, `below` its parent.
+  // A push stores the parent (LDS write, nobody waits) and a pop takes `below` and re-reads the entry under it -- a read
+  // whose result is not needed before the NEXT pop, so it travels with the face reads instead of being a round trip of
+  // its own at the head of every step of the walk (it was: 5 dependent LDS round trips per visible face, 2 per leaf;
+  // now 2 and 1).
   TOHC_DEV bool traverse(unsigned pass, unsigned w, unsigned f0, unsigned e0) {
     int sp = 1;
     bool ret = false;
-    m->stk[0] = (uint16_t)(f0 | (e0 << 8));
+    unsigned top = f0 | (e0 << 8), below = 0;
     const V3 ww = svW(w);
+#define TOHC_EPA_POP() do { --sp; top = below; below = sp >= 2 ? (unsigned)m->stk[sp - 2] : 0u; } while (0)
+#define TOHC_EPA_PUSH(parent, child) do { m->stk[sp - 1] = (uint16_t)(parent); below = (parent); top = (child); ++sp; } while (0)
     while (sp > 0) {
-      const unsigned ent = m->stk[sp - 1];
+      const unsigned ent = top;
       const unsigned f = ent & 255u, e = (ent >> 8) & 3u, stage = ent >> 10;
       const unsigned e1 = (e + 1) % 3, e2 = (e + 2) % 3;
       if (stage == 0) {
@@ -1263,27 +1270,23 @@ struct Epa {
               if (limF < TOHC_EPA_MAX_FACES) exhausted = true;
               ret = false;
             }
-            --sp;
+            TOHC_EPA_POP();
           } else {
             ((uint8_t *)&m->fcp[f])[3] = (uint8_t)pass;
-            m->stk[sp - 1] = (uint16_t)(f | (e << 8) | (1u << 10));
-            if (sp >= MEM::kNF) { ret = false; --sp; continue; }  // cannot happen: depth <= hull faces
-            m->stk[sp] = (uint16_t)(byteOf(fw, e1) | (byteOf(ew, e1) << 8));
-            ++sp;
+            if (sp >= MEM::kNF) { ret = false; TOHC_EPA_POP(); continue; }  // cannot happen: depth <= hull faces
+            TOHC_EPA_PUSH(f | (e << 8) | (1u << 10), byteOf(fw, e1) | (byteOf(ew, e1) << 8));
           }
         } else {
           ret = false;
-          --sp;
+          TOHC_EPA_POP();
         }
       } else if (stage == 1) {
         if (ret) {
           const uint32_t fw = m->ff[f], ew = m->fe[f];
-          m->stk[sp - 1] = (uint16_t)(f | (e << 8) | (2u << 10));
-          m->stk[sp] = (uint16_t)(byteOf(fw, e2) | (byteOf(ew, e2) << 8));
-          ++sp;
+          TOHC_EPA_PUSH(f | (e << 8) | (2u << 10), byteOf(fw, e2) | (byteOf(ew, e2) << 8));
         } else {
           ret = false;
-          --sp;
+          TOHC_EPA_POP();
         }
       } else {
         if (ret) {
@@ -1292,9 +1295,11 @@ struct Epa {
           ret = true;
         } else
           ret = false;
-        --sp;
+        TOHC_EPA_POP();
       }
     }
+#undef TOHC_EPA_POP
+#undef TOHC_EPA_PUSH
     return ret;
   }
   // The fan of new faces over the horizon m->hz[0 .. hnf), w = the new vertex: face k = (c[e+1], c[e], w) of horizon
