@@ -1062,8 +1062,22 @@ static int launchTail(tohc_engine *e) {
   return TOHC_OK;
 }
 
-static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren, const std::vector<int> &h_qchildren, CallParams cp,
-                        bool robotMode, int slot, bool append) {
+// One pass's head in three steps, so that two passes can share ONE broadphase launch (enqueueBoth): narrowPrepare (the
+// lane, its queues, the counters, the kernel arguments), narrowBroadphase, narrowFinish (k_exact, k_gjk, k_gjk_cont, the
+// books, the tail).
+struct NarrowLaunch {
+  int slot = 0, laneIdx = 0, nQ = 0;
+  bool wantJ = false, noSlab = false, append = false, robotMode = false, unitAll = false;
+  CallParams cp;
+  hipStream_t s = nullptr;
+  hipEvent_t *ev = nullptr;
+  tohc_engine::OpenHead oh;
+  CullArgs ca;
+  size_t blocks = 0;
+  const std::vector<int> *h_qchildren = nullptr;
+};
+static int narrowPrepare(tohc_engine *e, const DynMap &dm, const int *d_qchildren, const std::vector<int> &h_qchildren, CallParams cp, bool robotMode,
+                         int slot, bool append, NarrowLaunch &L) {
   const int nQ = (int)h_qchildren.size();
   const int K = robotMode ? e->K : 1;
   // one slab, one layout: the enqueue that starts a slab fixes whether it carries gradient rows (and of which robot
@@ -1112,7 +1126,9 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
   HIPCHK(e->d_records.reserve(e->max_records));
   HIPCHK(e->d_grads.reserve(e->max_records * 2 * (size_t)K));
   HIPCHK(hipEventRecord(ev[2], s));
-  tohc_engine::OpenHead oh;
+  L.slot = slot; L.laneIdx = laneIdx; L.nQ = nQ; L.wantJ = wantJ; L.noSlab = noSlab; L.append = append; L.robotMode = robotMode;
+  L.s = s; L.ev = ev; L.h_qchildren = &h_qchildren;
+  tohc_engine::OpenHead &oh = L.oh;
   oh.slot = slot; oh.lane = laneIdx; oh.empty = !(nQ > 0 && cp.n_cast_sets > 0);
   const bool sep1 = cp.gap == 0 && cp.cast;  // poses mode keeps the end-of-sweep poses in their own tables
   NarrowArgs &a = oh.a;
@@ -1124,15 +1140,20 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
   a.dofs = robotMode ? e->d_dofs.p : nullptr;
   a.pairs = ln.pairs.p; a.cands = ln.cands.p; a.epaq = ln.epaq.p; a.penq = ln.penq.p; a.distq = ln.distq.p; a.contq = ln.contq.p; a.hits = ln.hits.p; a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p; a.rec_base = e->d_rec_base.p + slot;
   a.records = e->d_records.p; a.grads = e->d_grads.p; a.dbg = e->d_dbg.p;
+  L.cp = cp;
+  memset(&L.ca, 0, sizeof L.ca);
+  L.unitAll = false;
+  L.blocks = 0;
   if (!oh.empty) {
-    const size_t blocks = (size_t)cp.n_cast_sets * nQ;
-    if (blocks > 0x7fffffffull) return fail(e, TOHC_E_CAPACITY, "broadphase grid too large (%zu blocks)", blocks);
-    CullArgs ca;
+    L.blocks = (size_t)cp.n_cast_sets * nQ;
+    if (L.blocks > 0x7fffffffull) return fail(e, TOHC_E_CAPACITY, "broadphase grid too large (%zu blocks)", L.blocks);
+    CullArgs &ca = L.ca;
     ca.a = a; ca.qchildren = d_qchildren; ca.nQ = nQ;
     ca.dynAabb0 = e->d_dynAabb.p; ca.dynAabb1 = sep1 ? e->d_dynAabb1.p : e->d_dynAabb.p;
     ca.dynSph0 = e->d_dynSph.p;
     ca.pretest = e->pretest;
     ca.defer_exact = 0;
+    ca.dyn_elsewhere = 0;
     ca.dbg = getenv("TOHC_BP_DBG") ? atoi(getenv("TOHC_BP_DBG")) : 0;
     // Who scans what (k_broadphase_unit's comment): when all a unit's box tests fit a few dozen rounds of one wavefront
     // (a small world; in "poses" mode every child moves and there is no static table), a wavefront per unit takes them
@@ -1140,30 +1161,41 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
     // moving children.  (Giving only the moving children of a large world to the unit kernel was measured too: no gain,
     // 0.72 vs 0.69 ms per launch on config 4.)
     const bool unitOk = e->unit_broadphase > 0 && cp.n_cast_sets >= e->unit_broadphase && nQ <= TOHC_BPU_MAX_Q && (unsigned)e->n_children < TOHC_BPU_MAX_CHILD && ca.dbg == 0;
-    const bool unitAll = unitOk && (size_t)nQ * ((dm.n_stat > 0 ? dm.n_stat_pad : 0) + dm.n_dyn_children) <= 64 * 96;
-    const bool unitDyn = false;
-    if (unitAll) {
-      CullArgs cu = ca;
-      cu.dyn_elsewhere = 1;   // (for this kernel: 1 = the static children are its own too)
-      if (cp.cast) hipLaunchKernelGGL((k_broadphase_unit<true>), dim3((unsigned)cp.n_cast_sets), dim3(TOHC_BP_THREADS), 0, s, cu);
-      else hipLaunchKernelGGL((k_broadphase_unit<false>), dim3((unsigned)cp.n_cast_sets), dim3(TOHC_BP_THREADS), 0, s, cu);
-    }
-    ca.dyn_elsewhere = unitDyn ? 1 : 0;
-    if (!unitAll) {
-      // the exact stage of the pre-test in a kernel of its own, a lane per pair (k_exact), when there are enough
-      // wavefronts for it to matter
-      ca.defer_exact = (e->defer_exact && ca.pretest && TOHC_BP_EXACT && ca.dbg == 0) ? 1 : 0;
-      if (ca.defer_exact) {
-        if (cp.cast) hipLaunchKernelGGL((k_broadphase<true, true>), dim3((unsigned)blocks), dim3(TOHC_BP_THREADS), 0, s, ca);
-        else hipLaunchKernelGGL((k_broadphase<false, true>), dim3((unsigned)blocks), dim3(TOHC_BP_THREADS), 0, s, ca);
-      } else {
-        if (cp.cast) hipLaunchKernelGGL((k_broadphase<true, false>), dim3((unsigned)blocks), dim3(TOHC_BP_THREADS), 0, s, ca);
-        else hipLaunchKernelGGL((k_broadphase<false, false>), dim3((unsigned)blocks), dim3(TOHC_BP_THREADS), 0, s, ca);
-      }
-      if (ca.defer_exact) {
-        if (cp.cast) hipLaunchKernelGGL((k_exact<true>), dim3(TOHC_EXACT_GRID), dim3(64), 0, s, ca);
-        else hipLaunchKernelGGL((k_exact<false>), dim3(TOHC_EXACT_GRID), dim3(64), 0, s, ca);
-      }
+    L.unitAll = unitOk && (size_t)nQ * ((dm.n_stat > 0 ? dm.n_stat_pad : 0) + dm.n_dyn_children) <= 64 * 96;
+    // the exact stage of the pre-test in a kernel of its own, a lane per pair (k_exact)
+    if (!L.unitAll) ca.defer_exact = (e->defer_exact && ca.pretest && TOHC_BP_EXACT && ca.dbg == 0) ? 1 : 0;
+  }
+  return TOHC_OK;
+}
+static int narrowBroadphase(tohc_engine *e, NarrowLaunch &L) {
+  (void)e;
+  if (L.oh.empty) return TOHC_OK;
+  const CallParams &cp = L.cp;
+  hipStream_t s = L.s;
+  if (L.unitAll) {
+    CullArgs cu = L.ca;
+    cu.dyn_elsewhere = 1;   // (for this kernel: 1 = the static children are its own too)
+    if (cp.cast) hipLaunchKernelGGL((k_broadphase_unit<true>), dim3((unsigned)cp.n_cast_sets), dim3(TOHC_BP_THREADS), 0, s, cu);
+    else hipLaunchKernelGGL((k_broadphase_unit<false>), dim3((unsigned)cp.n_cast_sets), dim3(TOHC_BP_THREADS), 0, s, cu);
+  } else if (L.ca.defer_exact) {
+    if (cp.cast) hipLaunchKernelGGL((k_broadphase<true, true>), dim3((unsigned)L.blocks), dim3(TOHC_BP_THREADS), 0, s, L.ca);
+    else hipLaunchKernelGGL((k_broadphase<false, true>), dim3((unsigned)L.blocks), dim3(TOHC_BP_THREADS), 0, s, L.ca);
+  } else {
+    if (cp.cast) hipLaunchKernelGGL((k_broadphase<true, false>), dim3((unsigned)L.blocks), dim3(TOHC_BP_THREADS), 0, s, L.ca);
+    else hipLaunchKernelGGL((k_broadphase<false, false>), dim3((unsigned)L.blocks), dim3(TOHC_BP_THREADS), 0, s, L.ca);
+  }
+  return TOHC_OK;
+}
+static int narrowFinish(tohc_engine *e, NarrowLaunch &L) {
+  const CallParams &cp = L.cp;
+  hipStream_t s = L.s;
+  hipEvent_t *ev = L.ev;
+  tohc_engine::Lane &ln = e->lane[L.laneIdx];
+  const NarrowArgs &a = L.oh.a;
+  if (!L.oh.empty) {
+    if (!L.unitAll && L.ca.defer_exact) {
+      if (cp.cast) hipLaunchKernelGGL((k_exact<true>), dim3(TOHC_EXACT_GRID), dim3(64), 0, s, L.ca);
+      else hipLaunchKernelGGL((k_exact<false>), dim3(TOHC_EXACT_GRID), dim3(64), 0, s, L.ca);
     }
     HIPCHK(hipEventRecord(ev[3], s));
     const int gridN = 256 * 8;
@@ -1187,17 +1219,26 @@ static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren
   }
   HIPCHK(hipEventRecord(ev[4], s));
   HIPCHK(hipEventRecord(ln.head_done, s));
-  e->open.push_back(oh);
+  e->open.push_back(L.oh);
   tohc_engine::Pending pd;
-  pd.slot = slot;
-  pd.aabb_tests = countAabbTests(e, h_qchildren, cp);
+  pd.slot = L.slot;
+  pd.aabb_tests = countAabbTests(e, *L.h_qchildren, cp);
   e->pending.push_back(pd);
   e->sorted_valid = false;
-  if (!append || noSlab) { e->last_robot_mode = robotMode; e->last_want_jac = wantJ; }
-  if (!append) e->slab_state = 0;   // a new slab is being filled
+  if (!L.append || L.noSlab) { e->last_robot_mode = L.robotMode; e->last_want_jac = L.wantJ; }
+  if (!L.append) e->slab_state = 0;   // a new slab is being filled
   e->last_T = cp.T;
   if ((int)e->open.size() >= e->max_open) return launchTail(e);
   return TOHC_OK;
+}
+static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren, const std::vector<int> &h_qchildren, CallParams cp,
+                        bool robotMode, int slot, bool append) {
+  NarrowLaunch L;
+  int rc = narrowPrepare(e, dm, d_qchildren, h_qchildren, cp, robotMode, slot, append, L);
+  if (rc != TOHC_OK) return rc;
+  rc = narrowBroadphase(e, L);
+  if (rc != TOHC_OK) return rc;
+  return narrowFinish(e, L);
 }
 
 // ContinuousCheckTrajectory: one k_sweep launch writes the records itself (no pair list, no k_finish); always a new slab
