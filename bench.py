@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak
-CATS = {"k_broadphase": "broadphase", "k_exact": "broadphase", "k_gjk": "gjk", "k_gjk_cont": "gjk", "k_pen": "epa", "k_epa": "epa", "k_tail_pen": "epa", "k_tail_epa": "epa",
+CATS = {"k_broadphase": "broadphase", "k_broadphase_both": "broadphase", "k_exact": "broadphase", "k_gjk": "gjk", "k_gjk_cont": "gjk", "k_pen": "epa", "k_epa": "epa", "k_tail_pen": "epa", "k_tail_epa": "epa",
         "k_finish": "finish", "k_tail_finish": "finish"}
 
 
@@ -271,6 +271,9 @@ def main():
     ap.add_argument("--hot-path-only", action="store_true",
                     help="skip the side measurements (host-delivered rate, single-problem latency, ContinuousCheckTrajectory) so that every "
                          "launch a profiler sees belongs to the timed workload: the command the profiles/ summaries are made with")
+    ap.add_argument("--two-calls", action="store_true",
+                    help="enqueue the two passes of a linearization with tohc_enqueue_links_vs_all + tohc_enqueue_cast_vs_all (each with a "
+                         "broadphase launch of its own) instead of tohc_enqueue_linearization")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: rank set-up, partition and reductions over gloo with a stub engine")
     args = ap.parse_args()
     if args.problems_per_gpu is None:
@@ -302,9 +305,16 @@ def main():
     T = dofs.shape[1]
     eng = cc.eng
 
+    def linearize():
+        # one SQP linearization: the discrete (LinksVsAll) and the cast (CastVsAll, gap 1) collision cost of every timestep
+        if args.two_calls:
+            eng.enqueue_links_vs_all(-1, True, append=False)
+            eng.enqueue_cast_vs_all(1, True, append=True)
+        else:
+            eng.enqueue_linearization(-1, 1, True)      # the same slab, one broadphase launch for both passes
+
     def step():
-        eng.enqueue_links_vs_all(-1, True, append=False)
-        eng.enqueue_cast_vs_all(1, True, append=True)
+        linearize()
         eng.sync()
 
     def barrier():
@@ -363,22 +373,19 @@ def main():
         # problems, as a multi-start job runs: batch i+1 computes while batch i's block is assembled and copied.
         dp = 0.05
         eng.stage_dofs(dofs, P, T)
-        eng.enqueue_links_vs_all(-1, True, append=False)
-        eng.enqueue_cast_vs_all(1, True, append=True)
+        linearize()
         h = eng.fetch_hinges(dp, dp, copy=False)           # warm-up: buffers
         ta = time.perf_counter()
         pe = 0
         for _ in range(3):
             eng.stage_dofs(dofs, P, T)
-            eng.enqueue_links_vs_all(-1, True, append=False)
-            eng.enqueue_cast_vs_all(1, True, append=True)
+            linearize()
             h = eng.fetch_hinges(dp, dp, copy=False)
             pe += eng.counters()["pair_evals"]
         hinge_sync = pe / (time.perf_counter() - ta)
         hbytes = int(h["n_rows"] * 20 + h["nnz"] * 12 + (len(h["col_off"]) + len(h["row_off"])) * 8)
         eng.stage_dofs(dofs, P, T)
-        eng.enqueue_links_vs_all(-1, True, append=False)
-        eng.enqueue_cast_vs_all(1, True, append=True)
+        linearize()
         NB = 16
         pe = 0
         for b in range(NB + 2):
@@ -388,8 +395,7 @@ def main():
             eng.fetch_hinges_begin(dp, dp)                 # waits for batch i; its counters are final
             pe += eng.counters()["pair_evals"]
             eng.stage_dofs(dofs, P, T)                     # batch i+1
-            eng.enqueue_links_vs_all(-1, True, append=False)
-            eng.enqueue_cast_vs_all(1, True, append=True)
+            linearize()
             h = eng.fetch_hinges_end(copy=False)           # batch i in host memory while batch i+1 computes
         hinge_pipe = pe / (time.perf_counter() - ta)
         eng.sync()
@@ -401,8 +407,7 @@ def main():
         pe = 0
         for _ in range(3):
             eng.stage_dofs(dofs, P, T)
-            eng.enqueue_links_vs_all(-1, True, append=False)
-            eng.enqueue_cast_vs_all(1, True, append=True)
+            linearize()
             eng.fetch(copy=False)
             pe += eng.counters()["pair_evals"]
         api = pe / (time.perf_counter() - ta)
@@ -411,8 +416,7 @@ def main():
         lat = []
         for _ in range(10):
             tl = time.perf_counter()
-            eng.enqueue_links_vs_all(-1, True, append=False)
-            eng.enqueue_cast_vs_all(1, True, append=True)
+            linearize()
             eng.fetch(copy=False)
             lat.append((time.perf_counter() - tl) * 1e3)
         lat_ms = float(np.median(lat))

@@ -146,6 +146,15 @@ int tohc_cast_vs_all_batch(tohc_engine *e, const double *dofs, int B, int T, int
 int tohc_stage_dofs(tohc_engine *e, const double *dofs, int B, int T);
 int tohc_enqueue_links_vs_all(tohc_engine *e, int filter_mask, int want_jacobians, int append);
 int tohc_enqueue_cast_vs_all(tohc_engine *e, int gap, int want_jacobians, int append);
+
+/* One SQP linearization of a problem with a discrete and a continuous collision term (CollisionCostInfo::hatch,
+ * problem_description.cpp:516-529: one CollisionCost per timestep, over (i) or over (i, i + gap); the two constructors,
+ * collision_terms.cpp:196-205, make a SingleTimestepCollisionEvaluator or a CastCollisionEvaluator; python_examples/
+ * benchmark.py:76-118 asks for both kinds).  A NEW slab holding exactly what
+ *   tohc_enqueue_links_vs_all(e, filter_mask, want_jacobians, 0);  tohc_enqueue_cast_vs_all(e, gap, want_jacobians, 1);
+ * enqueue -- same records, gradient rows and counters -- with one broadphase launch for both passes where the engine's
+ * set-up allows (the cast pass's query boxes hold the discrete pass's). */
+int tohc_enqueue_linearization(tohc_engine *e, int filter_mask, int gap, int want_jacobians);
 int tohc_sync(tohc_engine *e);
 int tohc_fetch(tohc_engine *e, const tohc_record **records, const double **grads, int *n_records);
 

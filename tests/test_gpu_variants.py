@@ -220,3 +220,54 @@ def test_fetch_device_and_device_all_gather(built):
         assert n0 > 0 and d_g0 == 0 and rowd0 == 0
     finally:
         e.close()
+
+
+def test_enqueue_linearization_equals_the_two_enqueues(built):
+    """tohc_enqueue_linearization = tohc_enqueue_links_vs_all(append 0) + tohc_enqueue_cast_vs_all(append 1): the same slab
+    and the same counters, with the two passes' broadphases in one launch (k_broadphase_both) or, where the engine's
+    set-up does not allow that (TOHC_FUSE_BP=0, one stream, an enqueue cut into unit ranges), one after the other."""
+    from trajopt_amd import engine
+    s, rb, static_T = _world()
+    Bp, Tt = 5, 30
+    dofs = np.stack([synth.fullbody_trajectory(rb, np.random.default_rng(80 + b), Tt) for b in range(Bp)])
+    keys = ("aabb_tests", "pair_evals", "gjk_evals", "epa_evals", "contacts")
+    for env in ({}, {"TOHC_FUSE_BP": "0"}, {"TOHC_STREAMS": "1"}, {"TOHC_CHUNKS": "2", "TOHC_STREAMS": "4"}, {"TOHC_MERGE_TAIL": "1"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            e = engine.Engine(0)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        try:
+            e.upload_scene(s, static_T)
+            e.upload_robot(rb)
+            e.set_contact_distance(0.09)
+            e.set_capacity(1 << 22, 1 << 20)
+            e.stage_dofs(dofs, Bp, Tt)
+            for mask, gap in ((-1, 1), (M.GROUP_KINBODY, 3), (-1, Tt)):   # (gap = T: no cast unit at all)
+                e.enqueue_links_vs_all(mask, True, append=False)
+                e.enqueue_cast_vs_all(gap, True, append=True)
+                r0, g0 = e.fetch()
+                c0 = e.counters()
+                e.enqueue_linearization(mask, gap, True)
+                r1, g1 = e.fetch()
+                c1 = e.counters()
+                tag = "%s mask %d gap %d" % (env, mask, gap)
+                assert len(r0) > (1000 if gap < Tt else 100), tag
+                assert np.array_equal(r0, r1) and np.array_equal(g0, g1), tag
+                assert all(c0[k] == c1[k] for k in keys), (tag, [(k, c0[k], c1[k]) for k in keys])
+            # a third pass appended to a linearization, like to any slab
+            e.enqueue_linearization(-1, 1, True)
+            e.enqueue_links_vs_all(M.GROUP_KINBODY, True, append=True)
+            r2, _ = e.fetch()
+            e.enqueue_links_vs_all(-1, True, append=False)
+            e.enqueue_cast_vs_all(1, True, append=True)
+            e.enqueue_links_vs_all(M.GROUP_KINBODY, True, append=True)
+            r3, _ = e.fetch()
+            assert np.array_equal(r2, r3), env
+        finally:
+            e.close()

@@ -139,6 +139,8 @@ struct tohc_engine {
   int n_lanes = 4;                   // TOHC_STREAMS=1..4
   int chunks = 1;                    // a large enqueue is cut into this many unit ranges, one per lane (TOHC_CHUNKS)
   hipEvent_t ev_fk = nullptr;        // the FK of the staged DOF vectors has finished (main stream)
+  hipEvent_t ev_prep = nullptr, ev_fused = nullptr;   // tohc_enqueue_linearization: the first pass's lane is ready / the shared broadphase has finished
+  int fuse_broadphase = 1;           // TOHC_FUSE_BP=0: tohc_enqueue_linearization launches the two passes' broadphases separately
   // Passes whose head (broadphase + GJK) is on its lane and whose tail (penetration, EPA, record ranges, k_finish) is
   // still to be launched: the tail kernels take ALL open passes in one launch each (launchTail), which is what fills
   // the chip -- one pass alone queues fewer penetration pairs than the GPU has wave slots.  A tail goes out when
@@ -326,7 +328,9 @@ int tohc_create(tohc_engine **out, int device) {
   if (const char *pt = getenv("TOHC_GJK_SPLIT")) e->gjk_split = std::max(0, atoi(pt));
   if (const char *ns = getenv("TOHC_STREAMS")) e->n_lanes = std::min(std::max(atoi(ns), 1), 4);
   if (const char *nc = getenv("TOHC_CHUNKS")) e->chunks = std::min(std::max(atoi(nc), 1), 4);
-  if (hipEventCreateWithFlags(&e->ev_fk, hipEventDisableTiming) != hipSuccess) { tohc_destroy(e); return TOHC_E_HIP; }
+  if (hipEventCreateWithFlags(&e->ev_fk, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_prep, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_fused, hipEventDisableTiming) != hipSuccess) { tohc_destroy(e); return TOHC_E_HIP; }
+  if (const char *fb = getenv("TOHC_FUSE_BP")) e->fuse_broadphase = atoi(fb) != 0;
   for (auto &ln : e->lane)
     if (hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ln.done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ln.head_done, hipEventDisableTiming) != hipSuccess) {
@@ -380,6 +384,8 @@ void tohc_destroy(tohc_engine *e) {
   if (e->ev_slab_read) (void)hipEventDestroy(e->ev_slab_read);
   if (e->ev_hinge_small) (void)hipEventDestroy(e->ev_hinge_small);
   if (e->ev_fk) (void)hipEventDestroy(e->ev_fk);
+  if (e->ev_prep) (void)hipEventDestroy(e->ev_prep);
+  if (e->ev_fused) (void)hipEventDestroy(e->ev_fused);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -1396,6 +1402,90 @@ static int enqueueRobot(tohc_engine *e, int gap, int cast, int filter_mask, int 
     if (rc != TOHC_OK) return rc;
   }
   return TOHC_OK;
+}
+
+// tohc_enqueue_linearization: a new slab with the discrete pass (LinksVsAll, filter_mask) and the cast pass (CastVsAll,
+// gap) of one SQP linearization -- what tohc_enqueue_links_vs_all(append = 0) followed by tohc_enqueue_cast_vs_all(append
+// = 1) enqueue, same records, same counters -- with ONE broadphase launch for both passes when the engine's set-up allows
+// it (k_broadphase_both), else as those two calls.
+static int enqueueBoth(tohc_engine *e, int filter_mask, int gap, int want_jac) {
+  if (!e) return TOHC_E_INVALID;
+  if (!e->staged) return fail(e, TOHC_E_STATE, "stage the DOF vectors first (tohc_stage_dofs)");
+  if (gap < 1) return fail(e, TOHC_E_INVALID, "cast: gap must be >= 1");
+  const int B = e->staged_B, T = e->staged_T;
+  const bool fuse = e->fuse_broadphase && e->n_lanes >= 2 && e->chunks == 1 && e->defer_exact && e->pretest && T > gap && !getenv("TOHC_BP_DBG");
+  if (!fuse) {
+    const int rc = enqueueRobot(e, 0, 0, filter_mask, want_jac, 0);
+    return rc != TOHC_OK ? rc : enqueueRobot(e, gap, 1, -1, want_jac, 1);
+  }
+  HIPCHK(hipSetDevice(e->device));
+  if ((int)e->pending.size() + 2 > RING) {
+    const int rc = syncEngine(e);
+    if (rc != TOHC_OK) return rc;
+  }
+  const int slotD = (int)e->pending.size(), slotC = slotD + 1;
+  const size_t n_sets = (size_t)B * T;
+  DynMap dm = dynMapRobot(e);
+  int rc = launchTail(e);   // (their k_finish kernels read the pose tables too)
+  if (rc != TOHC_OK) return rc;
+  {   // FK, as every enqueue that starts a slab
+    hipEvent_t *ev = &e->events[(size_t)slotD * NEV];
+    hipStream_t s = e->stream;
+    for (auto &ln : e->lane) HIPCHK(hipStreamWaitEvent(s, ln.done, 0));   // pending enqueues still read the tables
+    HIPCHK(hipEventRecord(ev[0], s));
+    hipLaunchKernelGGL(k_fk, dim3((unsigned)n_sets), dim3(64), (size_t)e->n_links * 7 * sizeof(double), s, devRobot(e), devScene(e), dm, e->d_dofs.p,
+                       (int)n_sets, e->d, e->d_linkQT.p, e->d_objQT.p, e->d_dynXf.p, e->d_dynAabb.p, e->d_linkZ.p, e->d_dynSph.p);
+    HIPCHK(hipEventRecord(ev[1], s));
+    HIPCHK(hipEventRecord(e->ev_fk, s));
+    e->fk_done = true;
+  }
+  CallParams cpD, cpC;
+  memset(&cpD, 0, sizeof cpD);
+  cpD.T = T; cpD.gap = 0; cpD.cast = 0; cpD.filter_mask = filter_mask; cpD.want_jac = want_jac; cpD.d = e->d; cpD.breaking = e->breaking;
+  cpD.unit_base = 0; cpD.n_cast_sets = B * T;
+  cpC = cpD;
+  cpC.gap = gap; cpC.cast = 1; cpC.filter_mask = -1; cpC.n_cast_sets = B * (T - gap);
+  e->last_sets = (int64_t)n_sets;
+  e->slab_B = B; e->slab_disc_passes = 1; e->slab_cast_passes = 1; e->slab_gap = gap;
+  NarrowLaunch LD, LC;
+  rc = narrowPrepare(e, dm, e->d_qchildrenR.p, e->h_qchildrenR, cpD, true, slotD, false, LD);
+  if (rc != TOHC_OK) return rc;
+  // (what the first pass's narrowFinish will say about the slab, already now: the second pass is prepared before it)
+  e->slab_state = 0; e->last_robot_mode = true; e->last_want_jac = LD.wantJ;
+  {
+    hipStream_t ls = e->lane[slotC % e->n_lanes].stream;
+    hipEvent_t *evc = &e->events[(size_t)slotC * NEV];
+    HIPCHK(hipEventRecord(evc[0], ls));
+    HIPCHK(hipEventRecord(evc[1], ls));
+  }
+  rc = narrowPrepare(e, dm, e->d_qchildrenR.p, e->h_qchildrenR, cpC, true, slotC, true, LC);
+  if (rc != TOHC_OK) {   // the first pass alone, so that the engine's books stay whole
+    (void)narrowBroadphase(e, LD);
+    (void)narrowFinish(e, LD);
+    return rc;
+  }
+  const bool both = !LD.oh.empty && !LC.oh.empty && !LD.unitAll && !LC.unitAll && LD.ca.defer_exact && LC.ca.defer_exact && LD.laneIdx != LC.laneIdx &&
+                    LD.nQ == LC.nQ;
+  if (both) {
+    BothArgs ba;
+    ba.d = LD.ca; ba.c = LC.ca;
+    HIPCHK(hipEventRecord(e->ev_prep, LD.s));          // the first pass's counters are cleared
+    HIPCHK(hipStreamWaitEvent(LC.s, e->ev_prep, 0));
+    hipLaunchKernelGGL(k_broadphase_both, dim3((unsigned)LD.blocks), dim3(TOHC_BP_THREADS), 0, LC.s, ba);
+    HIPCHK(hipEventRecord(e->ev_fused, LC.s));
+    HIPCHK(hipStreamWaitEvent(LD.s, e->ev_fused, 0));
+    rc = narrowFinish(e, LD);
+    if (rc != TOHC_OK) return rc;
+    return narrowFinish(e, LC);
+  }
+  rc = narrowBroadphase(e, LD);
+  if (rc == TOHC_OK) rc = narrowFinish(e, LD);
+  if (rc != TOHC_OK) return rc;
+  rc = narrowBroadphase(e, LC);
+  return rc != TOHC_OK ? rc : narrowFinish(e, LC);
+}
+int tohc_enqueue_linearization(tohc_engine *e, int filter_mask, int gap, int want_jacobians) {
+  return enqueueBoth(e, filter_mask, gap, want_jacobians);
 }
 
 int tohc_enqueue_links_vs_all(tohc_engine *e, int filter_mask, int want_jacobians, int append) {

@@ -699,6 +699,189 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase(C
 }
 
 // -----------------------------------------------------------------------------------------------------------------
+// k_broadphase_both: the broadphase of a linearization's discrete AND cast pass in one launch (tohc_enqueue_linearization).
+// The cast pass's query box (the boxes at t and t + gap joined) holds the discrete pass's (the box at t); the sphere
+// stage of both pre-tests looks from the other child's sphere to the query's origin at t, and the swept shape's reach
+// is the larger of the reaches at the two poses, the first of which is the discrete pass's.  So one wavefront per
+// (discrete unit, query child) scans once with the larger box, notes per survivor whether the smaller box overlaps
+// too, drains once and feeds both passes' candidate lists (d = the discrete pass's arguments, c = the cast pass's; each
+// with its own counters and list; ONLY with the exact stage deferred, unit ranges whole, same query children).  Per pass
+// the survivors, counts and lists are what k_broadphase<false> / <true> produce: same tests, same arithmetic.
+// -----------------------------------------------------------------------------------------------------------------
+struct BothArgs { CullArgs d, c; };
+#define TOHC_BP_DFLAG 0x20000000   // queue entries: the discrete pass's (smaller) box overlaps too
+__global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase_both(BothArgs ba) {
+  const CullArgs &cd = ba.d, &cc = ba.c;
+  const NarrowArgs &a = cd.a;   // (scene, maps, pose tables: the same in both)
+  const DevScene &sc = a.sc;
+  const DynMap &dm = a.dm;
+  const CallParams &cpd = cd.a.cp, &cpc = cc.a.cp;
+  __shared__ int s_q[TOHC_BP_QCAP];
+  const int lane = threadIdx.x;
+  const int qi = blockIdx.x % cd.nQ;
+  const int u = blockIdx.x / cd.nQ;          // the discrete pass's unit = pose set (problem * T + t)
+  const int T = cpd.T, gap = cpc.gap;
+  const int prob = u / T, t = u % T;
+  const bool hasCast = t < T - gap;          // wave-uniform
+  const int csC = prob * (T - gap) + t;      // the cast pass's unit
+  const int set0 = u, set1 = u + gap;
+  const TOHC_CONST_AS int *qinfo = uniformPtr(cd.qchildren + 4 * qi);   // (child, object, moving slot or -1, 0)
+  const int q = qinfo[0], Q = qinfo[1], qs = qinfo[2];
+  const int shard = blockIdx.x % TOHC_NSHARD;
+  const Aabb bqD = qs >= 0 ? ldAabbU(cd.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + qs) * 6) : ldAabbU(sc.stat_aabb + 6 * q);
+  Aabb bq = bqD;
+  if (hasCast && qs >= 0) bq = aabbUnion(bqD, ldAabbU(cc.dynAabb1 + ((size_t)set1 * dm.n_dyn_children + qs) * 6));
+  const unsigned char *allowedRow = sc.allowed + (size_t)Q * sc.n_objects;
+  const float lim = cpd.d * 1.01f + 1.0e-4f;
+  unsigned int nq = 0, ncandD = 0, ncandC = 0;   // wave-uniform
+  Cvx<1> cq;
+  Xf tq;
+  loadSideU(a, q, set0, set1, hasCast, cq, tq, qs);   // (cq.cast / cq.t01 only with a cast unit)
+  Aabb bd0;
+  bd0.lo = mk(1.f, 1.f, 1.f); bd0.hi = mk(-1.f, -1.f, -1.f);
+  if (lane < dm.n_dyn_children) bd0 = ldAabb(cd.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + lane) * 6);
+
+  auto drain = [&]() __attribute__((always_inline)) {
+    __syncthreads();
+    for (unsigned int k0 = 0; k0 < nq; k0 += TOHC_BP_THREADS) {
+      const unsigned int k = k0 + lane;
+      bool keepD = false, keepC = false;
+      int x = 0, xSlot = 0;
+      bool xDyn = false;
+      V3 c = mk(0.f, 0.f, 0.f);
+      float rad = 0.f;
+      if (k < nq) {
+        const int ent = s_q[k];
+        x = ent & ~(TOHC_BP_DYN | TOHC_BP_DFLAG);
+        xDyn = (ent & TOHC_BP_DYN) != 0;
+        xSlot = x;
+        const CullSph sx = xDyn ? cd.dynSph0[(size_t)set0 * dm.n_dyn_children + x] : sc.stat_sph[x];
+        if (xDyn) x = dm.dyn_children[x];
+        const int X = sx.obj, gx = sx.group;
+        c = mk(sx.c[0], sx.c[1], sx.c[2]);
+        rad = sx.r;
+        const bool allowed = allowedRow[X] != 0;
+        // (k_broadphase's filters: the discrete pass skips the query object itself, the swept shape meets everything)
+        keepD = (ent & TOHC_BP_DFLAG) != 0 && X != Q && (gx & (short)cpd.filter_mask) != 0 && allowed;
+        keepC = hasCast && (gx & TOHC_GROUP_KINBODY) != 0 && allowed;
+      }
+      ncandD += (unsigned int)__popcll(__ballot(keepD));
+      ncandC += (unsigned int)__popcll(__ballot(keepC));
+      if (keepD || keepC) {
+        const V3 dir = tq.o - c;
+        const float dl2 = len2(dir);
+        if (dl2 > 1.0e-12f) {
+          const float dl = sqrtf(dl2);
+          const V3 dL = mulVM(-dir, tq.b);
+          // the plain shape's reach at the first pose: the discrete pass's, and (a sphere's radius aside) the first of the swept shape's two
+          const float eD = plainReach<true>(cq, dL, false);
+          if (keepD) {
+            const float deltaS = dl2 - eD - (rad + shapeMargin<1>(cq)) * dl;
+            if (deltaS > 0.0f && deltaS > lim * dl) keepD = false;
+          }
+          if (keepC) {
+            const float e0 = cq.kind == KIND_SPHERE ? plainReach<true>(cq, dL, true) : eD;
+            const float e1 = plainReach<true>(cq, mulVM(dL, cq.t01.b), true) + dot(dL, cq.t01.o);
+            const float deltaS = dl2 - fmaxf(e0, e1) - rad * dl;
+            if (deltaS > 0.0f && deltaS > lim * dl) keepC = false;
+          }
+        }
+      }
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const bool keep = pass ? keepC : keepD;
+        const NarrowArgs &ap = pass ? cc.a : cd.a;
+        const unsigned long long m = __ballot(keep);
+        const unsigned int cnt = (unsigned int)__popcll(m);
+        if (cnt > 0) {
+          unsigned int base = 0;
+          if (lane == 0) base = atomicAdd(&ap.cnt->sh[shard].n_exact, cnt);
+          base = __shfl(base, 0);
+          if (keep) {
+            const unsigned int pos = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+            if (pos < ap.cp.seg_cap) {
+              PairRec p;
+              p.set = pass ? csC : u; p.q = q; p.x = x; p.pad = xDyn ? xSlot + 1 : 0;
+              ap.cands[(size_t)shard * ap.cp.seg_cap + pos] = p;
+            } else {
+              ap.cnt->overflow = 1;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    nq = 0;
+  };
+  auto push = [&](bool hit, int ent) __attribute__((always_inline)) {
+    const unsigned long long m = __ballot(hit);
+    if (hit) s_q[nq + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = ent;
+    nq += (unsigned int)__popcll(m);
+    if (nq > TOHC_BP_QCAP - TOHC_BP_THREADS) drain();
+  };
+
+  for (int cb = 0; cb < dm.n_cl; cb += TOHC_BP_THREADS) {
+    const int c = cb + lane;
+    bool over = false;
+    if (c < dm.n_cl) {
+      const float *tt = dm.cl_soa + c;
+      const int P = dm.n_cl_pad;
+      Aabb bc;
+      bc.lo = mk(tt[0], tt[P], tt[2 * P]);
+      bc.hi = mk(tt[3 * P], tt[4 * P], tt[5 * P]);
+      over = aabbOverlap(bq, bc);
+    }
+    unsigned long long cm = __ballot(over);
+    while (cm) {
+      int ccn[4];
+      float bb[4][6];
+      int ch[4];
+      const int P = dm.n_stat_pad;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        ccn[v] = -1;
+        if (cm) { ccn[v] = cb + (int)__builtin_ctzll(cm); cm &= cm - 1; }
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        if (ccn[v] >= 0) {
+          const int i = ccn[v] * 64 + lane;
+          const float *tt = dm.stat_soa + i;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) bb[v][k] = tt[k * P];
+          ch[v] = dm.stat_children[i];
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        if (ccn[v] >= 0) {
+          Aabb bx;
+          bx.lo = mk(bb[v][0], bb[v][1], bb[v][2]);
+          bx.hi = mk(bb[v][3], bb[v][4], bb[v][5]);
+          const bool hit = aabbOverlap(bq, bx);
+          push(hit, hit ? (ch[v] | (aabbOverlap(bqD, bx) ? TOHC_BP_DFLAG : 0)) : 0);
+        }
+      }
+    }
+  }
+  if (dm.n_dyn_children > 0)
+    push(lane < dm.n_dyn_children && aabbOverlap(bq, bd0), lane | TOHC_BP_DYN | (aabbOverlap(bqD, bd0) ? TOHC_BP_DFLAG : 0));
+  for (int base = TOHC_BP_THREADS; base < dm.n_dyn_children; base += TOHC_BP_THREADS) {
+    const int i = base + lane;
+    bool hit = false, hitD = false;
+    if (i < dm.n_dyn_children) {
+      const Aabb bx = ldAabb(cd.dynAabb0 + ((size_t)set0 * dm.n_dyn_children + i) * 6);
+      hit = aabbOverlap(bq, bx);
+      hitD = aabbOverlap(bqD, bx);
+    }
+    push(hit, i | TOHC_BP_DYN | (hitD ? TOHC_BP_DFLAG : 0));
+  }
+  if (nq > 0) drain();
+  if (lane == 0 && ncandD > 0) atomicAdd(&cd.a.cnt->sh[shard].n_cand, ncandD);
+  if (lane == 0 && ncandC > 0) atomicAdd(&cc.a.cnt->sh[shard].n_cand, ncandC);
+}
+
+// -----------------------------------------------------------------------------------------------------------------
 // k_exact: the exact stage of k_broadphase's pre-test, ONE LANE per pair the sphere stage passed (NarrowArgs.cands).
 // Same direction (query origin - the other child's bounding-sphere centre, read from the same record), same support
 // points, same test as the stage inside the broadphase kernels: the pair list k_gjk gets holds the same pairs.

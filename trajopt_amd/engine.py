@@ -69,6 +69,7 @@ SYMBOLS = {
     "tohc_stage_dofs": (C.c_int, [C.c_void_p, _f64p, C.c_int, C.c_int]),
     "tohc_enqueue_links_vs_all": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "tohc_enqueue_cast_vs_all": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "tohc_enqueue_linearization": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "tohc_sync": (C.c_int, [C.c_void_p]),
     "tohc_fetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(_f64p), C.POINTER(C.c_int)]),
     "tohc_fetch_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -231,6 +232,11 @@ class Engine:
 
     def enqueue_cast_vs_all(self, gap=1, want_jacobians=True, append=False):
         self._chk(self.lib.tohc_enqueue_cast_vs_all(self.h, int(gap), int(want_jacobians), int(append)))
+
+    def enqueue_linearization(self, filter_mask=-1, gap=1, want_jacobians=True):
+        """A new slab = enqueue_links_vs_all(filter_mask, append=False) + enqueue_cast_vs_all(gap, append=True), with one
+        broadphase launch for both passes where the engine can (tohc_enqueue_linearization)."""
+        self._chk(self.lib.tohc_enqueue_linearization(self.h, int(filter_mask), int(gap), int(want_jacobians)))
 
     def sync(self):
         self._chk(self.lib.tohc_sync(self.h))
