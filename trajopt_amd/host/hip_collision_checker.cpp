@@ -517,8 +517,9 @@ void HIPCollisionChecker::PrefetchTrajectory(Configuration& rad, const TrajArray
   cast = cast && T >= 2;
   UploadRobot(*m_bound);
   chk(tohc_stage_dofs(m_e, traj.data(), 1, T));
-  if (discrete) chk(tohc_enqueue_links_vs_all(m_e, filterMask, 1, 0));
-  if (cast) chk(tohc_enqueue_cast_vs_all(m_e, 1, 1, discrete ? 1 : 0));
+  if (discrete && cast) chk(tohc_enqueue_linearization(m_e, filterMask, 1, 1));   // both passes, one broadphase launch
+  else if (discrete) chk(tohc_enqueue_links_vs_all(m_e, filterMask, 1, 0));
+  else if (cast) chk(tohc_enqueue_cast_vs_all(m_e, 1, 1, 0));
   const tohc_record* r;
   const double* g;
   int n;
