@@ -205,7 +205,8 @@ def profile_numbers(config):
             for kn, cat in CATS.items():
                 if "tohc::" + kn + "<" in row["kernel"] or "tohc::" + kn + "(" in row["kernel"]:
                     d = out.setdefault(cat, {})
-                    d.setdefault("_tb", []).append((float(row["hbm_bytes_per_launch"]), int(row["launches"]), kn))
+                    per_pass = 0.5 if kn == "k_broadphase_both" else 1.0   # (one launch serves both passes of a step)
+                    d.setdefault("_tb", []).append((float(row["hbm_bytes_per_launch"]) * per_pass, int(row["launches"]), kn))
         out["traffic_source"] = os.path.relpath(f, ROOT)
     f = newest("_sq_pmc.csv")
     if f:
@@ -472,7 +473,8 @@ def main():
                            "hbm_traffic_bytes_per_pass": prof.get(k, {}).get("traffic"), "valu_busy": prof.get(k, {}).get("valu_busy"),
                            "waves_per_simd": prof.get(k, {}).get("waves_per_simd")}
         dom = max(alg_b, key=lambda k: ms[k])
-        kname = {"broadphase": "k_broadphase", "gjk": "k_gjk", "epa": "k_pen+k_epa", "finish": "k_finish"}[dom]
+        kname = {"broadphase": ("k_broadphase" if args.two_calls else "k_broadphase_both") + "+k_exact", "gjk": "k_gjk+k_gjk_cont",
+                 "epa": "k_tail_pen+k_tail_epa", "finish": "k_finish"}[dom]
         step_s = dt_max / args.steps
         step_flops = 2 * sum(alg_f.values())
         step_bytes = 2 * sum(alg_b.values())

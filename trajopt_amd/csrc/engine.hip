@@ -1474,6 +1474,7 @@ static int enqueueBoth(tohc_engine *e, int filter_mask, int gap, int want_jac) {
     hipLaunchKernelGGL(k_broadphase_both, dim3((unsigned)LD.blocks), dim3(TOHC_BP_THREADS), 0, LC.s, ba);
     HIPCHK(hipEventRecord(e->ev_fused, LC.s));
     HIPCHK(hipStreamWaitEvent(LD.s, e->ev_fused, 0));
+    HIPCHK(hipEventRecord(LD.ev[2], LD.s));   // the shared launch is booked on the second pass only (cum_ms_broadphase adds the passes up)
     rc = narrowFinish(e, LD);
     if (rc != TOHC_OK) return rc;
     return narrowFinish(e, LC);
