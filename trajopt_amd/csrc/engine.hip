@@ -990,7 +990,7 @@ static int64_t countAabbTests(const tohc_engine *e, const std::vector<int> &qchi
 #define TOHC_FINISH_G 4   // lanes per hit in k_finish: most of a hit's work is the same for every lane of its group (measured per launch: 16 lanes 0.38 ms, 8: 0.29, 4: 0.22, 2: 0.23, 1: 0.20 but 73 KB of LDS rows per block at K = 18)
 #endif
 #ifndef TOHC_FINISH_BLOCKS_PER_CU
-#define TOHC_FINISH_BLOCKS_PER_CU 4   // with TOHC_FINISH_WAVES 4 (128 VGPRs): four waves per SIMD = 4 blocks of 256 per CU (measured: 2 -> 3 blocks +5 %, 4 / 4 another +3 %)
+#define TOHC_FINISH_BLOCKS_PER_CU 2   // with TOHC_FINISH_WAVES 2: two waves per SIMD = 2 blocks of 256 per CU, the whole grid resident at once (measured step: 1 block 2.41 ms, 2: 2.31, 3: 2.35, 4: 2.34, 8: 2.32)
 #endif
 // The tail of every open pass: ONE k_tail_pen and ONE k_tail_epa launch over all their penetration queues, their
 // record ranges reserved in enqueue order (k_tail_range), then each pass's k_finish on its own lane, side by side.
