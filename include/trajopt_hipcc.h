@@ -237,8 +237,9 @@ int tohc_ray_cast(tohc_engine *e, const double *dofs, const double *from, const 
 /* the same on explicit poses: obj_T [n_objects][7] */
 int tohc_ray_cast_poses(tohc_engine *e, const double *obj_T, const double *from, const double *to, int n_rays, float *closest_fraction);
 
-/* NO COUNTERPART IN THE REFERENCE.  tohc_ray_cast_poses for callers that cannot allocate (code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc): the same kernels and the same answers, but every
+/* NO COUNTERPART IN THE REFERENCE.  tohc_ray_cast_poses for callers that cannot allocate (tight serving loops, harnesses
+ * that forbid hipMalloc, code that must not disturb a HIP graph capture going on elsewhere in the process -- the call
+ * itself runs on the engine's private stream and waits for it, so it is not something to capture): the same kernels and the same answers, but every
  * pointer is DEVICE memory the caller owns (d_obj_T [n_objects][7], d_from / d_to [n_rays][3] doubles,
  * d_closest_fraction [n_rays] floats), and the working buffers (child poses, cull boxes, the fp32 ray table) live in a
  * fixed array inside the library's device image instead of the engine's grow-only buffers: the call makes no

@@ -2,10 +2,14 @@
 //
 //   host_unit box_distance        the reference's TEST(collision_checker, box_distance), collision-checker-unit.cpp:29-90
 //   host_unit continuous_boxes    the reference's TEST(continuous_collisions, boxes),    collision-checker-unit.cpp:102-153
-//   host_unit linearize IN OUT    the collision terms (CollisionCost / CollisionConstraint over SingleTimestep- and
-//                                 CastCollisionEvaluator, collision_terms.cpp) on a world + trajectory written by
-//                                 tests/util.py:write_flat_world, per-timestep and prefetched; every contact and affine
-//                                 expression is dumped to OUT, where pytest compares them with the oracle.
+//   host_unit linearize IN OUT    one SQP evaluation of a problem with a discrete and a continuous collision term per
+//                                 timestep (problem_description.cpp:516-529) on a world + trajectory written by
+//                                 tests/util.py:write_flat_world: the driver below asks the checker what the reference's
+//                                 collision terms ask it (LinksVsAll per timestep, CastVsAll per pair), once call by call
+//                                 and once behind a CollisionPrefetchCost; every contact and hinge row is dumped to OUT,
+//                                 where pytest compares them with the Python host and the oracle.
+//   host_unit fk_guard            UploadRobot refuses a kinematic tree whose device FK does not reproduce GetTransform()
+//   host_unit grab_rebind         Grab / Release between two evaluators on the same robot and joints
 // The environment is built from plain structs (rave_shim.hpp) because OpenRAVE and its XML loader are absent; the box
 // bodies below are data/box.xml and data/boxbot.xml (a 1 m cube each).
 #include <cstdio>
@@ -13,7 +17,7 @@
 #include <fstream>
 #include <sstream>
 
-#include "collision_terms_standin.hpp"
+#include "collision_prefetch_cost.hpp"
 #include "hip_collision_checker.hpp"
 
 using namespace OR;
@@ -36,7 +40,7 @@ static KinBodyPtr makeBox(const string& name) {   // data/box.xml
   KinBody::LinkPtr l = b->AddLink(name);
   KinBody::Link::Geometry g;
   g.type = GT_Box, g.boxExtents = Vector(.5, .5, .5);
-  l->m_geoms.push_back(g);
+  l->AddGeometry(g);
   return b;
 }
 static RobotBasePtr makeBoxbot() {   // data/boxbot.xml
@@ -44,7 +48,7 @@ static RobotBasePtr makeBoxbot() {   // data/boxbot.xml
   KinBody::LinkPtr l = r->AddLink("boxlink", RobotBase::Joint());
   KinBody::Link::Geometry g;
   g.type = GT_Box, g.boxExtents = Vector(.5, .5, .5);
-  l->m_geoms.push_back(g);
+  l->AddGeometry(g);
   return r;
 }
 
@@ -229,11 +233,11 @@ static void addGeoms(KinBody::Link& link, const Flat& F, int obj) {
       }
       default: throw std::runtime_error("flat world: unsupported shape kind");
     }
-    link.m_geoms.push_back(g);
+    link.AddGeometry(g);
   }
-  bool compound = !(link.m_geoms.size() == 1 && fabs(link.m_geoms[0].t.rot.x - 1) < 1e-6 && fabs(link.m_geoms[0].t.rot.y) < 1e-6 &&
-                    fabs(link.m_geoms[0].t.rot.z) < 1e-6 && fabs(link.m_geoms[0].t.rot.w) < 1e-6 && fabs(link.m_geoms[0].t.trans.x) < 1e-6 &&
-                    fabs(link.m_geoms[0].t.trans.y) < 1e-6 && fabs(link.m_geoms[0].t.trans.z) < 1e-6);
+  const Transform& g0 = link.m_geoms[0]->t;
+  bool compound = !(link.m_geoms.size() == 1 && fabs(g0.rot.x - 1) < 1e-6 && fabs(g0.rot.y) < 1e-6 && fabs(g0.rot.z) < 1e-6 && fabs(g0.rot.w) < 1e-6 &&
+                    fabs(g0.trans.x) < 1e-6 && fabs(g0.trans.y) < 1e-6 && fabs(g0.trans.z) < 1e-6);
   if (compound != (F.at("obj_compound")[obj] != 0)) throw std::runtime_error("flat world: object's compound flag is not what the reference's rule gives");
 }
 
@@ -301,38 +305,110 @@ static World loadWorld(const string& path) {
   return W;
 }
 
-static void dumpExpr(FILE* f, const AffExpr& e) {
-  fprintf(f, " %.17g %d", e.constant, (int)e.coeffs.size());
-  for (size_t i = 0; i < e.coeffs.size(); ++i) fprintf(f, " %d %.17g", e.vars[i].var_index, e.coeffs[i]);
-}
+// ---- the driver: one SQP evaluation of the problem's collision terms ---------------------------------------------------
+// A collision term of the problem: the discrete cost of timestep t, or the continuous cost of the pair (t, t + 1)
+// (CollisionCostInfo::hatch makes one of each kind per timestep, problem_description.cpp:516-529).  The reference's term
+// objects live in collision_terms.cpp, which upstream stays as it is; what this driver restates is only WHAT THEY ASK the
+// checker and what they make of the answer -- one row per contact,
+//     discrete:  dist(x) ~ const0 + grad0 . x_t
+//     cast:      dist(x) ~ (1 - time) (const0 + grad0 . x_t) + time (const1 + grad1 . x_{t+1})      (collision_terms.cpp:64-80)
+// turned into the hinge argument dist_pen - dist(x) (:205-214) and the value sum coeff max(0, dist_pen - dist) (:215-223).
+struct Term { bool cast; int t; };
+struct Row {   // constant + sum coeffs[i] * x[vars[i]]
+  double constant;
+  vector<int> vars;
+  DblVec coeffs;
+  double at(const DblVec& x) const {
+    double v = constant;
+    for (size_t i = 0; i < vars.size(); ++i) v += coeffs[i] * x[vars[i]];
+    return v;
+  }
+};
+
+struct TermDriver {
+  CollisionCheckerPtr cc;
+  RobotAndDOFPtr rad;
+  vector<KinBody::LinkPtr> links;   // GetAffectedLinks(only_with_geom): what the evaluators query (collision_terms.cpp:100-115)
+  int K;
+  double dist_pen, coeff;
+  TermDriver(World& W) : cc(CollisionChecker::GetOrCreate(*W.env)), rad(W.rad), K(W.traj.cols()), dist_pen(W.dist_pen), coeff(W.coeff) {
+    vector<int> inds;
+    rad->GetAffectedLinks(links, true, inds);
+  }
+  DblVec dofs(const DblVec& x, int t) const { return DblVec(x.begin() + (size_t)t * K, x.begin() + (size_t)(t + 1) * K); }
+  // the checker call of one term (collision_terms.cpp:118-122 / :156-161)
+  vector<Collision> contacts(const Term& m, const DblVec& x) const {
+    vector<Collision> out;
+    if (m.cast) {
+      rad->SetDOFValues(dofs(x, m.t));
+      cc->CastVsAll(*rad, links, dofs(x, m.t), dofs(x, m.t + 1), out);
+    } else {
+      cc->BindConfiguration(*rad);   // the one line a maintainer adds to SingleTimestepCollisionEvaluator
+      rad->SetDOFValues(dofs(x, m.t));
+      cc->LinksVsAll(links, out, -1);
+    }
+    return out;
+  }
+  double value(const vector<Collision>& cs) const {
+    double v = 0;
+    for (const Collision& c : cs) v += std::max(0.0, dist_pen - c.distance) * coeff;
+    return v;
+  }
+  // hinge argument dist_pen - dist(x) of every contact, from the linearization the checker put into the Collision
+  vector<Row> hinges(const Term& m, const vector<Collision>& cs) const {
+    vector<Row> out;
+    for (const Collision& c : cs) {
+      if ((int)c.grad0.size() != K || (m.cast && (int)c.grad1.size() != K)) throw std::runtime_error("contact without a linearization");
+      Row r;
+      const float w0f = m.cast ? 1 - c.time : 1.0f;   // `1 - collisions[i].time` is float arithmetic in the reference (:73)
+      const double w0 = w0f, w1 = m.cast ? (double)c.time : 0.0;
+      r.constant = dist_pen - (m.cast ? w0 * c.const0 + w1 * c.const1 : c.const0);
+      for (int k = 0; k < K; ++k) r.vars.push_back(m.t * K + k), r.coeffs.push_back(m.cast ? -(w0 * c.grad0[k]) : -c.grad0[k]);
+      if (m.cast)
+        for (int k = 0; k < K; ++k) r.vars.push_back((m.t + 1) * K + k), r.coeffs.push_back(-(w1 * c.grad1[k]));
+      out.push_back(r);
+    }
+    return out;
+  }
+};
 
 struct Pass {
-  vector<vector<Collision> > contacts;   // per cost
-  vector<ConvexObjectivePtr> convex;
+  vector<vector<Collision> > contacts;   // per term
+  vector<vector<Row> > hinges;
   DblVec values;
 };
 
-static Pass runCosts(World& W, const DblVec& x, bool prefetch) {
-  int T = W.traj.rows(), K = W.traj.cols();
-  auto vars = [&](int t) {
-    VarVector v(K);
-    for (int k = 0; k < K; ++k) v[k] = Var(t * K + k);
-    return v;
-  };
-  vector<std::shared_ptr<CollisionCost> > costs;   // problem_description.cpp:551-566: one cost per timestep / per pair
-  for (int t = 0; t < T; ++t) costs.push_back(std::make_shared<CollisionCost>(W.dist_pen, W.coeff, W.rad, vars(t)));
-  for (int t = 0; t + 1 < T; ++t) costs.push_back(std::make_shared<CollisionCost>(W.dist_pen, W.coeff, W.rad, vars(t), vars(t + 1)));
-  HIPCollisionChecker* hip = dynamic_cast<HIPCollisionChecker*>(CollisionChecker::GetOrCreate(*W.env).get());
-  if (prefetch) hip->PrefetchTrajectory(*W.rad, W.traj, true, true);
-  Pass P;
-  for (auto& c : costs) {
-    P.values.push_back(c->value(x));    // evaluateCosts, optimizers.cpp:36-44
-    P.convex.push_back(c->convex(x));   // convexifyCosts, :50-56 (hits the evaluator's 3-entry cache)
-    vector<Collision> col;
-    c->GetEvaluator()->GetCollisionsCached(x, col);
-    P.contacts.push_back(col);
+// evaluateCosts then convexifyCosts over the cost list, in order (optimizers.cpp:36-56).  With `prefetch` the list starts
+// with a CollisionPrefetchCost, which is all it takes: nothing below calls PrefetchTrajectory.
+static Pass runCosts(World& W, const DblVec& x, bool prefetch, long* prefetchCalls = NULL) {
+  const int T = W.traj.rows(), K = W.traj.cols();
+  TermDriver D(W);
+  vector<Term> terms;
+  for (int t = 0; t < T; ++t) terms.push_back(Term{false, t});
+  for (int t = 0; t + 1 < T; ++t) terms.push_back(Term{true, t});
+  std::shared_ptr<CollisionPrefetchCost> pf;
+  if (prefetch) {
+    vector<VarVector> rows(T, VarVector(K));
+    for (int t = 0; t < T; ++t)
+      for (int k = 0; k < K; ++k) rows[t][k] = Var(t * K + k);
+    pf.reset(new CollisionPrefetchCost(W.rad, rows, true, true));
   }
+  Pass P;
+  Model model;
+  if (pf) EXPECT_TRUE(pf->value(x) == 0);                         // evaluateCosts: the prefetch cost comes first ...
+  for (const Term& m : terms) P.values.push_back(D.value(D.contacts(m, x)));
+  if (pf) EXPECT_TRUE(pf->convex(x, &model)->hinges.empty());     // convexifyCosts: ... and again (same x: no second GPU call)
+  for (const Term& m : terms) {
+    P.contacts.push_back(D.contacts(m, x));
+    P.hinges.push_back(D.hinges(m, P.contacts.back()));
+  }
+  if (pf && prefetchCalls) *prefetchCalls = pf->NumPrefetches();
   return P;
+}
+
+static void dumpRow(FILE* f, const Row& e) {
+  fprintf(f, " %.17g %d", e.constant, (int)e.coeffs.size());
+  for (size_t i = 0; i < e.coeffs.size(); ++i) fprintf(f, " %d %.17g", e.vars[i], e.coeffs[i]);
 }
 
 static void test_linearize(const string& in, const string& out) {
@@ -344,58 +420,68 @@ static void test_linearize(const string& in, const string& out) {
   for (const World::Grab& g : W.grabs) W.robot->GrabAt(g.body, W.robot->GetLinks()[g.link], g.rel);   // after the bodies were added, like a caller would
   int T = W.traj.rows(), K = W.traj.cols();
   DblVec x = W.traj.m_data;
+  const int nTerms = 2 * T - 1;
 
   long calls0 = hip->NumEngineCalls();
   Pass A = runCosts(W, x, false);
-  long callsA = hip->NumEngineCalls() - calls0, hits0 = hip->NumPrefetchHits();
-  Pass B = runCosts(W, x, true);
+  long callsA = hip->NumEngineCalls() - calls0, hits0 = hip->NumPrefetchHits(), pfCalls = 0;
+  Pass B = runCosts(W, x, true, &pfCalls);
   long callsB = hip->NumEngineCalls() - calls0 - callsA, hitsB = hip->NumPrefetchHits() - hits0;
-  EXPECT_EQ(callsA, (long)(2 * T - 1));   // one engine call per cost (value -> convex is an evaluator cache hit)
-  EXPECT_EQ(callsB, 1L);                  // the whole trajectory in one
-  EXPECT_EQ(hitsB, (long)(2 * T - 1));
-  // prefetched == per-timestep, bit for bit
+  // call by call: every term asks the checker in the evaluate pass and again in the convexify pass (the reference's
+  // evaluators memoise the second, cache.hxx; this driver does not), + the FK guard of the one robot upload
+  EXPECT_EQ(callsA, (long)(2 * nTerms + 1));
+  EXPECT_EQ(callsB, 1L);                  // behind the prefetch cost: the whole trajectory in ONE engine call ...
+  EXPECT_EQ(pfCalls, 1L);                 // ... made by its value(x); its convex(x) found the slab current
+  EXPECT_EQ(hitsB, (long)(2 * nTerms));   // and every term's two queries were answered from that slab
+  // prefetched == call by call.  Joint DOFs only: bit for bit.  With affine DOFs the call-by-call LinksVsAll reads the base
+  // angle back from the body transform (RaveGetAffineDOFValuesFromTransform, ~1e-16 off what was set), the prefetch has
+  // the exact vector: equal to that noise.
+  const bool exact = W.rad->affinedofs == 0;
   EXPECT_EQ(A.values.size(), B.values.size());
   for (size_t i = 0; i < A.values.size(); ++i) {
-    EXPECT_TRUE(A.values[i] == B.values[i]);
-    EXPECT_EQ(A.convex[i]->hinges.size(), B.convex[i]->hinges.size());
-    for (size_t h = 0; h < A.convex[i]->hinges.size() && h < B.convex[i]->hinges.size(); ++h) {
-      const AffExpr &a = A.convex[i]->hinges[h].first, &b = B.convex[i]->hinges[h].first;
-      EXPECT_TRUE(a.constant == b.constant && a.coeffs == b.coeffs);
+    EXPECT_TRUE(exact ? A.values[i] == B.values[i] : fabs(A.values[i] - B.values[i]) <= 1e-9 * (1 + fabs(B.values[i])));
+    EXPECT_EQ(A.hinges[i].size(), B.hinges[i].size());
+    for (size_t h = 0; h < A.hinges[i].size() && h < B.hinges[i].size(); ++h) {
+      const Row &a = A.hinges[i][h], &b = B.hinges[i][h];
+      if (exact || (int)i >= T) EXPECT_TRUE(a.constant == b.constant && a.coeffs == b.coeffs);   // (CastVsAll is handed its vectors: exact either way)
+      else {
+        EXPECT_NEAR(a.constant, b.constant, 1e-9);
+        for (size_t k = 0; k < a.coeffs.size() && k < b.coeffs.size(); ++k) EXPECT_NEAR(a.coeffs[k], b.coeffs[k], 1e-9);
+      }
     }
   }
   // the same hinges as the device assembles them (tohc_fetch_hinges on the slab the prefetch left) against
-  // what sco would hand BPMPD for the reference's cost objects: ConvexObjective::addHinge (modeling.cpp:22-29: row
-  // `viol - h <= 0`) -> BPMPDModel::optimize (bpmpd_interface.cpp:352-369: rhs = -constant; per variable the (row, value)
-  // list through simplify2, solver_interface.cpp:23-37: exact zeros dropped, rows ascending).  Bit for bit.
+  // what sco would hand BPMPD for these rows: ConvexObjective::addHinge (modeling.cpp:22-29: row `viol - h <= 0`) ->
+  // BPMPDModel::optimize (bpmpd_interface.cpp:352-369: rhs = -constant; per variable the (row, value) list through
+  // simplify2, solver_interface.cpp:23-37: exact zeros dropped, rows ascending).  Bit for bit.
   {
     tohc_hinges H;
     EXPECT_EQ(tohc_fetch_hinges(hip->GetEngine(), W.dist_pen, W.dist_pen, &H), (int)TOHC_OK);
     EXPECT_EQ((int)H.n_problems, 1);
     EXPECT_EQ((int)H.T, T);
     EXPECT_EQ((int)H.K, K);
-    // rows of the device block are in canonical order: (t, discrete before cast); the costs come discrete t = 0.., then cast
+    // rows of the device block are in canonical order: (t, discrete before cast); the terms come discrete t = 0.., then cast
     size_t nrows = 0;
-    for (auto& c : B.convex) nrows += c->hinges.size();
+    for (auto& c : B.hinges) nrows += c.size();
     EXPECT_EQ((size_t)H.n_rows, nrows);
-    vector<int> rowOfHinge;   // device row of the h-th hinge in cost order
+    vector<int> rowOfHinge;   // device row of the h-th hinge in term order
     {
       vector<vector<int> > rowsOf(2 * T);   // [t] discrete, [T + t] cast
       for (int i = 0; i < (int)H.n_rows; ++i) rowsOf[(H.row_t[i] & TOHC_HINGE_CAST) ? T + (H.row_t[i] & ~TOHC_HINGE_CAST) : H.row_t[i]].push_back(i);
-      for (size_t ci = 0; ci < B.convex.size(); ++ci) {
-        EXPECT_EQ(rowsOf[ci].size(), B.convex[ci]->hinges.size());
+      for (size_t ci = 0; ci < B.hinges.size(); ++ci) {
+        EXPECT_EQ(rowsOf[ci].size(), B.hinges[ci].size());
         for (int r : rowsOf[ci]) rowOfHinge.push_back(r);
       }
     }
     if ((size_t)H.n_rows == nrows && rowOfHinge.size() == nrows) {
       std::map<int, std::map<int, double> > var2cnt;   // var -> (row -> value), what simplify2 leaves
       size_t h = 0;
-      for (auto& c : B.convex)
-        for (auto& hg : c->hinges) {
-          const AffExpr& aff = hg.first;
+      for (auto& c : B.hinges)
+        for (const Row& aff : c) {
           const int row = rowOfHinge[h++];
           EXPECT_TRUE(H.rhs[row] == -aff.constant);
           for (size_t j = 0; j < aff.coeffs.size(); ++j)
-            if (aff.coeffs[j] != 0) var2cnt[aff.vars[j].var_index][row] += aff.coeffs[j];
+            if (aff.coeffs[j] != 0) var2cnt[aff.vars[j]][row] += aff.coeffs[j];
         }
       size_t nnz = 0;
       for (int v = 0; v < T * K; ++v) {
@@ -421,21 +507,9 @@ static void test_linearize(const string& in, const string& out) {
     EXPECT_EQ(A.values.size(), C.values.size());
     for (size_t i = 0; i < A.values.size() && i < C.values.size(); ++i) EXPECT_TRUE(A.values[i] == C.values[i]);
   }
-  // CollisionConstraint is the same arithmetic scaled by coeff (collision_terms.cpp:244-262)
-  {
-    VarVector v(K);
-    for (int k = 0; k < K; ++k) v[k] = Var((T / 2) * K + k);
-    CollisionConstraint cnt(W.dist_pen, W.coeff, W.rad, v);
-    DblVec val = cnt.value(x);
-    ConvexConstraintsPtr cc = cnt.convex(x);
-    EXPECT_EQ(val.size(), cc->ineqs.size());
-    double sum = 0;
-    for (size_t i = 0; i < val.size(); ++i) {
-      sum += val[i];
-      if (val[i] > 0) EXPECT_NEAR(cc->ineqs[i].value(x), val[i], 1e-9);   // the linearization is exact at x
-    }
-    EXPECT_NEAR(sum, A.values[T / 2], 1e-12);
-  }
+  // the linearization is exact at x: every hinge row evaluates to dist_pen - distance there
+  for (size_t i = 0; i < B.hinges.size(); ++i)
+    for (size_t h = 0; h < B.hinges[i].size(); ++h) EXPECT_NEAR(B.hinges[i][h].at(x), W.dist_pen - B.contacts[i][h].distance, 1e-9);
 
   FILE* f = fopen(out.c_str(), "w");
   if (!f) throw std::runtime_error("cannot write " + out);
@@ -449,7 +523,7 @@ static void test_linearize(const string& in, const string& out) {
       fprintf(f, "contact %s %d %s %d %d %.9g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g", c.linkA->GetName().c_str(), c.childA,
               c.linkB->GetName().c_str(), c.childB, (int)c.cctype, c.time, c.distance, c.normalB2A.x, c.normalB2A.y, c.normalB2A.z, c.ptA.x, c.ptA.y, c.ptA.z,
               c.ptB.x, c.ptB.y, c.ptB.z, c.ptB1.x, c.ptB1.y, c.ptB1.z);
-      dumpExpr(f, B.convex[i]->hinges[h].first);   // the hinge argument dist_pen - dist(x), as addHinge received it
+      dumpRow(f, B.hinges[i][h]);   // the hinge argument dist_pen - dist(x)
       fprintf(f, "\n");
     }
   }
@@ -460,6 +534,142 @@ static void test_linearize(const string& in, const string& out) {
     fprintf(f, "sweep %s %d %s %d %.9g %.17g %.17g %.17g\n", c.linkA->GetName().c_str(), c.childA, c.linkB->GetName().c_str(), c.childB, c.const1,
             c.normalB2A.x, c.normalB2A.y, c.normalB2A.z);
   fclose(f);
+}
+
+// ---- a small arm for the two host-layer tests below: three revolute links with a box each, over a table ----------------
+static RobotBasePtr makeArm3() {
+  RobotBasePtr r(new RobotBase("arm3"));
+  double off = 0;
+  for (int i = 0; i < 3; ++i) {
+    RobotBase::Joint j;
+    j.parent = i - 1, j.type = JointRevolute, j.origin = Transform(Vector(1, 0, 0, 0), Vector(off, 0, i == 0 ? 0.5 : 0)), j.axis = Vector(0, i == 1 ? 1 : 0, i == 1 ? 0 : 1), j.dof = i;
+    std::ostringstream nm;
+    nm << "arm" << i;
+    KinBody::LinkPtr l = r->AddLink(nm.str(), j);
+    KinBody::Link::Geometry g;
+    g.type = GT_Box, g.boxExtents = Vector(.15, .03, .03), g.t = Transform(Vector(1, 0, 0, 0), Vector(.15, 0, 0));
+    l->AddGeometry(g);
+    off = 0.3;
+  }
+  r->SetDOFValues(DblVec{0.2, 0.3, -0.4});
+  return r;
+}
+static KinBodyPtr makeSlab(const string& name, const Vector& half, const Vector& at) {
+  KinBodyPtr b(new KinBody(name));
+  KinBody::LinkPtr l = b->AddLink(name);
+  KinBody::Link::Geometry g;
+  g.type = GT_Box, g.boxExtents = half;
+  l->AddGeometry(g);
+  b->SetTransform(Transform(Vector(1, 0, 0, 0), at));
+  return b;
+}
+
+// The FK guard (HIPCollisionChecker::CheckDeviceFK): the tree handed to tohc_upload_robot, run through the engine's FK
+// kernel, must reproduce every link->GetTransform().  Here the host's robot is made to disagree with the tree the checker
+// reads -- one joint origin is moved AFTER the host placed its links (the state stamp is not bumped, as a wrong convention
+// in rave_access would look) -- and the bind must throw; with the robot put right again it must not.
+static void test_fk_guard() {
+  EnvironmentBasePtr env(new EnvironmentBase);
+  RobotBasePtr arm = makeArm3();
+  env->Add(arm), env->Add(makeSlab("table", Vector(.8, .8, .01), Vector(.4, 0, .42)));
+  CollisionCheckerPtr checker = CollisionChecker::GetOrCreate(*env);
+  checker->SetContactDistance(.1f);
+  RobotAndDOFPtr rad(new RobotAndDOF(arm, IntVec{0, 1, 2}, 0, Vector(0, 0, 1), env));
+  vector<KinBody::LinkPtr> links;
+  vector<int> inds;
+  rad->GetAffectedLinks(links, true, inds);
+  DblVec q0{0.2, 0.3, -0.4}, q1{0.25, 0.35, -0.3};
+  vector<Collision> ok;
+  checker->CastVsAll(*rad, links, q0, q1, ok);   // binds, uploads, passes the guard
+  EXPECT_TRUE(!ok.empty() && (int)ok[0].grad0.size() == 3);
+  // (i) a tree that is not the robot's: joint 2 sits 5 mm from where the host's FK has it
+  RobotBase::Joint& j2 = const_cast<RobotBase::Joint&>(arm->GetJoints()[2]);
+  const Transform good = j2.origin;
+  j2.origin.trans.x += 0.005;
+  RobotAndDOFPtr rad2(new RobotAndDOF(arm, IntVec{0, 1}, 0, Vector(0, 0, 1), env));   // another active set: a new upload
+  vector<KinBody::LinkPtr> links2;
+  rad2->GetAffectedLinks(links2, true, inds);
+  bool threw = false;
+  try {
+    vector<Collision> c;
+    checker->CastVsAll(*rad2, links2, DblVec{0.2, 0.3}, DblVec{0.25, 0.35}, c);
+  } catch (const std::runtime_error& e) {
+    threw = string(e.what()).find("forward kinematics disagrees") != string::npos && string(e.what()).find("arm2") != string::npos;
+    if (!threw) printf("unexpected exception: %s\n", e.what());
+  }
+  EXPECT_TRUE(threw);
+  // (ii) put right again: the same bind goes through, and answers like the first one did for the shared pair of columns
+  j2.origin = good;
+  vector<Collision> again;
+  checker->CastVsAll(*rad2, links2, DblVec{0.2, 0.3}, DblVec{0.25, 0.35}, again);
+  EXPECT_TRUE(!again.empty() && (int)again[0].grad0.size() == 2);
+  // (iii) a mirrored axis convention (the classic): joint 1 about -y instead of +y
+  j2.origin = good;
+  RobotBase::Joint& j1 = const_cast<RobotBase::Joint&>(arm->GetJoints()[1]);
+  j1.axis = Vector(0, -1, 0);
+  RobotAndDOFPtr rad3(new RobotAndDOF(arm, IntVec{1, 2}, 0, Vector(0, 0, 1), env));
+  vector<KinBody::LinkPtr> links3;
+  rad3->GetAffectedLinks(links3, true, inds);
+  threw = false;
+  try {
+    vector<Collision> c;
+    checker->CastVsAll(*rad3, links3, DblVec{0.3, -0.4}, DblVec{0.35, -0.3}, c);
+  } catch (const std::runtime_error& e) {
+    threw = string(e.what()).find("forward kinematics disagrees") != string::npos;
+  }
+  EXPECT_TRUE(threw);
+  j1.axis = Vector(0, 1, 0);
+}
+
+// bind + LinksVsAll, then robot->Grab, then a NEW evaluator on the same robot and joints: the affected-link list
+// now holds the grabbed body's link (configuration_space.cpp:120-131) and the checker must follow -- linearized contacts,
+// not the explicit-pose route's bare ones; and back again after Release.
+static void test_grab_rebind() {
+  EnvironmentBasePtr env(new EnvironmentBase);
+  RobotBasePtr arm = makeArm3();
+  KinBodyPtr held = makeSlab("held", Vector(.05, .02, .02), Vector(0, 0, 5));
+  env->Add(arm), env->Add(makeSlab("table", Vector(.8, .8, .01), Vector(.4, 0, .42))), env->Add(held);
+  CollisionCheckerPtr checker = CollisionChecker::GetOrCreate(*env);
+  HIPCollisionChecker* hip = dynamic_cast<HIPCollisionChecker*>(checker.get());
+  checker->SetContactDistance(.1f);
+  DblVec q{0.2, 0.3, -0.4};
+  auto query = [&](size_t expectLinks, bool expectHeld) {
+    // what a fresh SingleTimestepCollisionEvaluator does (collision_terms.cpp:100-122)
+    RobotAndDOFPtr rad(new RobotAndDOF(arm, IntVec{0, 1, 2}, 0, Vector(0, 0, 1), env));
+    vector<KinBody::LinkPtr> links;
+    vector<int> inds;
+    rad->GetAffectedLinks(links, true, inds);
+    EXPECT_EQ(links.size(), expectLinks);
+    checker->BindConfiguration(*rad);
+    rad->SetDOFValues(q);
+    vector<Collision> c;
+    checker->LinksVsAll(links, c, -1);
+    EXPECT_TRUE(!c.empty());
+    bool sawHeld = false;
+    for (const Collision& col : c) {
+      EXPECT_EQ(col.grad0.size(), (size_t)3);   // the linearizing route: every contact carries its row
+      sawHeld |= col.linkA == held->GetLinks()[0].get() || col.linkB == held->GetLinks()[0].get();
+    }
+    EXPECT_TRUE(sawHeld == expectHeld);
+    // and the prefetch route follows too
+    TrajArray traj(2, 3);
+    for (int k = 0; k < 3; ++k) traj(0, k) = q[k], traj(1, k) = q[k] + 0.05;
+    hip->PrefetchTrajectory(*rad, traj, true, true);
+    long h0 = hip->NumPrefetchHits();
+    vector<Collision> c2;
+    rad->SetDOFValues(q);
+    checker->LinksVsAll(links, c2, -1);
+    EXPECT_EQ(hip->NumPrefetchHits(), h0 + 1);
+    EXPECT_EQ(c2.size(), c.size());
+  };
+  query(3, false);
+  // the held box: 12 cm past the last link's tip, a few centimetres above the table
+  arm->SetDOFValues(q);
+  arm->GrabAt(held, arm->GetLinks()[2], Transform(Vector(1, 0, 0, 0), Vector(.36, 0, 0)));
+  query(4, true);
+  arm->Release(held);
+  held->SetTransform(Transform(Vector(1, 0, 0, 0), Vector(0, 0, 5)));
+  query(3, false);
 }
 
 // CreateCollisionChecker's switch (TRAJOPT_COLLISION_CHECKER = hip | bullet): "bullet" and unknown names are errors, never a
@@ -492,7 +702,9 @@ int main(int argc, char** argv) {
     else if (cmd == "factory_hip") test_factory_hip();
     else if (cmd == "continuous_boxes") test_continuous_boxes();
     else if (cmd == "linearize" && argc == 4) test_linearize(argv[2], argv[3]);
-    else { fprintf(stderr, "usage: host_unit box_distance | continuous_boxes | linearize IN OUT\n"); return 2; }
+    else if (cmd == "fk_guard") test_fk_guard();
+    else if (cmd == "grab_rebind") test_grab_rebind();
+    else { fprintf(stderr, "usage: host_unit box_distance | continuous_boxes | factory_switch | factory_hip | fk_guard | grab_rebind | linearize IN OUT\n"); return 2; }
   } catch (const std::exception& e) {
     printf("EXCEPTION %s\n", e.what());
     return 3;

@@ -1,0 +1,56 @@
+// rave_access.hpp (STAND-IN implementation) -- everything HIPCollisionChecker needs from a robot that is not one of the
+// plain accessors the reference's own checker uses (GetLinks, GetGeometries, GetTransform, GetDOFValues, IsRobot, ...):
+//   * the kinematic tree in the flattened layout tohc_upload_robot takes (include/trajopt_hipcc.h),
+//   * the links of grabbed bodies with their poses in the grabbing link's frame.
+// hip_collision_checker.cpp touches the robot's internals ONLY through these functions.  This file implements them over
+// the test stand-in of OpenRAVE (rave_shim.hpp: RobotBase::GetJoints, GetGrabbedInfo, Link::m_rel); the implementation
+// over OpenRAVE's public API is trajopt_amd/host/openrave/rave_access.hpp -- the same declarations, selected by the
+// include path of the build.  UploadRobot checks whatever implementation it got against link->GetTransform() (the FK
+// guard), so a tree that does not reproduce the host's FK is refused at bind time.
+#pragma once
+#include <vector>
+
+#include "rave_shim.hpp"
+#include "trajopt_hipcc.h"
+
+namespace trajopt {
+namespace rave_access {
+
+struct TreeNode {
+  int parent;                       // node index, parents first; -1: hangs off the robot's base transform
+  int type;                         // TOHC_J_FIXED | TOHC_J_REVOLUTE | TOHC_J_PRISMATIC
+  OR::Transform origin;             // T_node = T_parent * origin * Motion(type, axis, mult * q[dof] + offs)
+  OR::Vector axis;                  // in the node's frame
+  int dof;                          // index into robot->GetDOFValues(), -1: none
+  double mult, offs;
+  const OR::KinBody::Link* link;    // the link whose frame this node is (NULL: an intermediate joint frame)
+};
+
+// The robot's kinematic tree.  Stand-in: one node per link, as RobotBase stores it.
+inline void FlattenRobot(const OR::RobotBase& r, std::vector<TreeNode>& nodes) {
+  const std::vector<OR::RobotBase::Joint>& J = r.GetJoints();
+  nodes.resize(J.size());
+  for (size_t i = 0; i < J.size(); ++i) {
+    TreeNode& n = nodes[i];
+    n.parent = J[i].parent, n.type = (int)J[i].type, n.origin = J[i].origin, n.axis = J[i].axis, n.dof = J[i].dof, n.mult = J[i].mult, n.offs = J[i].offs;
+    n.link = r.GetLinks()[i].get();
+  }
+}
+
+struct GrabbedLink {
+  const OR::KinBody::Link* link;    // a link (with or without geometry) of a body the robot has grabbed
+  const OR::KinBody::Link* grabber; // the robot link that holds it
+  OR::Transform poseInGrabber;      // grabber^-1 * link, constant while the grab lasts
+};
+inline void GrabbedLinks(const OR::RobotBase& r, std::vector<GrabbedLink>& out) {
+  out.clear();
+  for (const OR::RobotBase::Grabbed& g : r.GetGrabbedInfo())
+    for (const OR::KinBody::LinkPtr& l : g.body->GetLinks()) {
+      GrabbedLink gl;
+      gl.link = l.get(), gl.grabber = r.GetLinks()[g.link].get(), gl.poseInGrabber = g.rel * l->m_rel;   // exact: no round trip through world poses
+      out.push_back(gl);
+    }
+}
+
+}  // namespace rave_access
+}  // namespace trajopt

@@ -3,8 +3,8 @@
 // The HIP checker (trajopt_amd/host/hip_collision_checker.{hpp,cpp}) is written against the reference's own headers:
 //   Collision, CastCollisionType, CollisionFilterGroups, CollisionChecker   src/trajopt/collision_checker.{hpp,cpp}
 //   Configuration, RobotAndDOF                                              src/trajopt/configuration_space.{hpp,cpp}
-// and is called by the reference's own collision terms (collision_terms_standin.hpp stands in for those; the checker
-// never includes them).  Upstream keeps all of those files.  They need OpenRAVE, Boost and Eigen, none of which is in this image, so the
+// and is called by the reference's own collision terms (upstream: unchanged files; here tests/cpp/host_unit.cpp drives the
+// checker the way they do).  Upstream keeps all of those files.  They need OpenRAVE, Boost and Eigen, none of which is in this image, so the
 // tests compile the checker against THIS stand-in instead: the same declarations, name for name, over the OpenRAVE
 // stand-in types of rave_shim.hpp and a sliver of sco (Var, AffExpr, addHinge, addIneqCnt) as plain data, and the same
 // function bodies restated inline (each cites the reference lines it follows).  It earns no component credit and is
@@ -87,8 +87,10 @@ inline DblVec getDblVec(const DblVec& x, const VarVector& vars) {
   return out;
 }
 inline double pospart(double x) { return x > 0 ? x : 0; }
+struct Model {};            // solver_interface.hpp: the QP under construction (opaque here)
 struct ConvexObjective {   // modeling.hpp: only what CollisionCost::convex calls
   vector<std::pair<AffExpr, double> > hinges;
+  explicit ConvexObjective(Model* = NULL) {}
   void addHinge(const AffExpr& e, double coeff) { hinges.push_back(std::make_pair(e, coeff)); }
 };
 struct ConvexConstraints {
@@ -97,6 +99,20 @@ struct ConvexConstraints {
 };
 typedef std::shared_ptr<ConvexObjective> ConvexObjectivePtr;
 typedef std::shared_ptr<ConvexConstraints> ConvexConstraintsPtr;
+class Cost {   // modeling.hpp:94-110
+ public:
+  virtual double value(const vector<double>&) = 0;
+  virtual ConvexObjectivePtr convex(const vector<double>& x, Model* model) = 0;
+  virtual VarVector getVars() { return VarVector(); }
+  std::string name() { return name_; }
+  void setName(const std::string& name) { name_ = name; }
+  Cost() : name_("unnamed") {}
+  virtual ~Cost() {}
+
+ protected:
+  std::string name_;
+};
+typedef std::shared_ptr<Cost> CostPtr;
 
 // ---- collision_checker.hpp ------------------------------------------------------------------------------------------
 enum CastCollisionType { CCType_None, CCType_Time0, CCType_Time1, CCType_Between };
@@ -267,15 +283,12 @@ inline void RobotAndDOF::SetDOFValues(const DblVec& dofs) {   // :12-23
   } else {
     robot->SetDOFValues(dofs, joint_inds);
   }
-  robot->CacheAffineDOFValues(affinedofs, rotationaxis, DblVec(dofs.begin() + joint_inds.size(), dofs.end()));
 }
 
 inline DblVec RobotAndDOF::GetDOFValues() {   // :25-35
-  DblVec out, aff;
+  DblVec out;
   for (int j : joint_inds) out.push_back(robot->GetDOFValues().at(j));
-  if (affinedofs != 0 && robot->GetCachedAffineDOFValues(affinedofs, rotationaxis, aff)) {
-    out.insert(out.end(), aff.begin(), aff.end());
-  } else if (affinedofs != 0) {   // RaveGetAffineDOFValuesFromTransform
+  if (affinedofs != 0) {   // RaveGetAffineDOFValuesFromTransform: an angle set through SetDOFValues comes back to ~1e-16, not bit for bit
     const Transform& T = robot->GetTransform();
     if (affinedofs & OR::DOF_X) out.push_back(T.trans.x);
     if (affinedofs & OR::DOF_Y) out.push_back(T.trans.y);

@@ -1,9 +1,11 @@
-"""The C++ host layer (trajopt_amd/host: HIPCollisionChecker, evaluators, CollisionCost over the C-ABI) on the GPU.
+"""The C++ host layer (trajopt_amd/host: HIPCollisionChecker, CollisionPrefetchCost over the C-ABI) on the GPU.
 
 tests/cpp/host_unit is built by __graft_entry__.build().  Its first two commands ARE the reference's unit tests
-(collision-checker-unit.cpp:29-153); `linearize` runs the reference's collision terms (collision_terms.cpp) on a world
-written here and dumps every contact and hinge expression, which are compared bit for bit with the Python host mirror
-(same C-ABI underneath) and, to the north-star tolerances, with the CPU oracle.
+(collision-checker-unit.cpp:29-153); `linearize` asks the checker what the reference's collision terms ask it
+(collision_terms.cpp: LinksVsAll per timestep, CastVsAll per pair) on a world written here, call by call and behind a
+CollisionPrefetchCost, and dumps every contact and hinge row, which are compared bit for bit with the Python host mirror
+(same C-ABI underneath) and, to the north-star tolerances, with the CPU oracle; `fk_guard` / `grab_rebind` test the
+checker's FK guard and its re-binding after Grab / Release.
 """
 import os
 import subprocess
@@ -28,7 +30,7 @@ def _run(*args):
     return p.stdout
 
 
-@pytest.mark.parametrize("cmd", ["box_distance", "continuous_boxes", "factory_switch", "factory_hip"])
+@pytest.mark.parametrize("cmd", ["box_distance", "continuous_boxes", "factory_switch", "factory_hip", "fk_guard", "grab_rebind"])
 def test_reference_unit_tests_through_the_cpp_host(built, cmd):
     assert "PASSED" in _run(cmd)
 
@@ -94,7 +96,9 @@ def test_cpp_collision_terms_vs_python_host_and_oracle(built, tmp_path, cfg):
     meta, costs, sweep = util.read_host_unit_dump(fout)
     T, K = traj.shape
     assert (meta["T"], meta["K"]) == (T, K)
-    assert meta["calls_prefetched"] == 1 and meta["prefetch_hits"] == 2 * T - 1 and meta["calls_per_timestep"] == 2 * T - 1
+    # call by call: every term queries in the evaluate and in the convexify pass (+ the FK guard of the robot upload); behind
+    # the CollisionPrefetchCost: ONE engine call, every query answered from its slab
+    assert meta["calls_prefetched"] == 1 and meta["prefetch_hits"] == 2 * (2 * T - 1) and meta["calls_per_timestep"] == 2 * (2 * T - 1) + 1
 
     cc = CC.HIPCollisionChecker(s, static_T, None)
     cc.SetRobot(rb)

@@ -5,7 +5,8 @@ host / fall-back paths agree with the oracle.
     ranges on four lanes, host-side canonical sort, 16-lane-group GJK, one EPA group per wavefront, two passes sharing one penetration tail,
     EPA runs repeated on the full pools;
   * several appended enqueues in one slab (the lanes' ordering events);
-  * a robot with two joints on one optimisation column (mimic joint): k_finish's lane-per-column fall-back.
+  * a robot with two joints on one optimisation column (mimic joint): k_finish's lane-per-column fall-back;
+  * a robot with more than 64 optimisation columns: the same fall-back and tohc_fetch_hinges' wide column kernel.
 """
 import os
 
@@ -171,6 +172,70 @@ def test_mimic_joint_falls_back_to_column_walk(built):
             n += len(rec)
         assert n > 0
         w.close()
+    finally:
+        e.close()
+
+
+def test_wide_robot_more_than_64_columns(built):
+    """K = 70 active joints (> TOHC_FAST_JAC_MAXK = TOHC_HINGE_MAXK = 64): k_finish runs its lane-per-column epilogue
+    (linearizeAt; no LDS rows are requested for it) and tohc_fetch_hinges its one-thread-per-variable column kernel
+    (k_hinge_cols_wide).  A planar-ish snake of 70 revolute joints with alternating axes, one box per link, over a
+    table and between two posts: engine vs oracle, hinge block vs the host assembly (bit for bit)."""
+    from trajopt_amd import collision_checker as CC, engine
+    s = M.Scene()
+    r = M.RobotModel()
+    parent = r.add_link(-1, name="base")
+    NJ = 70
+    for i in range(NJ):
+        obj = s.add_object([(s.add_box(0.02, 0.012, 0.012), synth.T7((0.02, 0, 0)))], M.GROUP_ROBOT, name="seg%d" % i)
+        parent = r.add_link(parent, synth.T7((0.04 if i else 0.0, 0, 0.5 if i == 0 else 0.0)), M.J_REVOLUTE, (0, 0, 1) if i % 2 == 0 else (0, 1, 0),
+                            dof=i, obj=obj, name="seg%d" % i)
+    r.set_active(range(NJ))
+    ids, boxT = synth.add_boxes(s, [((1.5, 1.0, 0.01), synth.T7((1.2, 0, 0.44))), ((.05, .05, .3), synth.T7((1.0, 0.12, 0.6))), ((.05, .05, .3), synth.T7((1.9, -0.12, 0.6)))], name="obst")
+    s.finalize(); r.finalize()
+    assert r.K == NJ > 64
+    static_T = synth.static_poses(s, ids, boxT)
+    rng = np.random.default_rng(8)
+    Bp, Tt = 2, 6
+    dofs = np.stack([synth.straight_line(rng.uniform(-0.03, 0.03, NJ), rng.uniform(-0.05, 0.05, NJ), Tt) for _ in range(Bp)])
+    e = engine.Engine(0)
+    try:
+        e.upload_scene(s, static_T)
+        e.upload_robot(r)
+        # neighbouring segments touch by construction: exclude what touches at the zero pose, like IgnoreZeroStateSelfCollisions
+        e.set_contact_distance(0.1)
+        rec0, _ = e.links_vs_all_batch(np.zeros((1, NJ)), 1, 1, filter_mask=M.GROUP_ROBOT, want_jacobians=False)
+        allowed = np.ones((s.n_objects, s.n_objects), np.uint8)
+        allowed[rec0["idA"], rec0["idB"]] = 0
+        allowed[rec0["idB"], rec0["idA"]] = 0
+        e.set_allowed_matrix(allowed)
+        d = 0.08
+        e.set_contact_distance(d)
+        w = B.oracle_world(s)
+        w.set_contact_distance(d)
+        w.set_allowed(allowed)
+        n = 0
+        for cast in (False, True):
+            rec, g = e.cast_vs_all_batch(dofs, Bp, Tt, 1) if cast else e.links_vs_all_batch(dofs, Bp, Tt)
+            assert g.shape == (len(rec), 2, NJ)
+            for b in range(Bp):
+                orec, og = w.linearize(r, static_T, dofs[b], cast=cast)
+                sel = rec["problem"] == b
+                util.assert_same_linearization(rec[sel], g[sel], orec, og, "wide K cast=%s b=%d" % (cast, b))
+                n += len(orec)
+        assert n > 100
+        w.close()
+        # the hinge block of the wide robot (k_hinge_cols_wide) against the host assembly
+        e.stage_dofs(dofs, Bp, Tt)
+        e.enqueue_linearization(-1, 1, True)
+        rec, g = e.fetch()
+        h = e.fetch_hinges(0.05, 0.03)
+        ref = CC.bpmpd_collision_block(rec, g, Bp, Tt, NJ, 1, 0.05, 0.03)
+        for k in ("B", "T", "K", "gap", "n_rows", "nnz"):
+            assert h[k] == ref[k], k
+        for k in ("row_off", "rhs", "dist", "row_t", "col_off", "col_idx", "col_val"):
+            assert h[k].tobytes() == ref[k].tobytes(), k
+        assert h["nnz"] > 0
     finally:
         e.close()
 

@@ -240,6 +240,12 @@ def test_shape_hull_golden_fixture_bit_exact(built):
     lib = engine.load_library()
     v = np.zeros((3, 3), np.float32); t = np.array([[0, 1, 3]], np.int32)
     assert lib.tohc_shape_hull(v.ctypes.data_as(C.POINTER(C.c_float)), 3, t.ctypes.data_as(C.POINTER(C.c_int32)), 1, None, 0) == -1
+    # a mesh without triangles is an error (the reference asserts indices.size() >= 3, bullet_collision_checker.cpp:162), whatever
+    # its vertex count -- not HullLibrary's fall-back box for 60 unreferenced points
+    big = np.random.default_rng(0).normal(size=(60, 3)).astype(np.float32)
+    assert lib.tohc_shape_hull(big.ctypes.data_as(C.POINTER(C.c_float)), 60, t.ctypes.data_as(C.POINTER(C.c_int32)), 0, None, 0) == -1
+    with pytest.raises(engine.EngineError):
+        engine.shape_hull(big, np.zeros((0, 3), np.int32))
 
 
 @pytest.mark.skipif(not B.ref_available(), reason="oracle/_ref/libref.so is only built where /root/reference exists")

@@ -28,14 +28,16 @@ def test_noalloc_ray_cast_equals_allocating_entry_point(built):
             b = rng.uniform(-1.5 * spread, 1.5 * spread, (n, 3))
             a[:20] = poses[rng.integers(0, len(poses), 20), 4:7]   # rays that start inside objects
             b[20:25] = a[20:25]                                    # zero-length rays
-            want = e.ray_cast_poses(poses, a, b)
             dT = torch.tensor(np.ascontiguousarray(poses, np.float64), device="cuda:0")
             da = torch.tensor(a, dtype=torch.float64, device="cuda:0")
             db = torch.tensor(b, dtype=torch.float64, device="cuda:0")
             out = torch.full((n + 8,), -7.0, dtype=torch.float32, device="cuda:0")   # 8 guard words past the end
             torch.cuda.synchronize()
+            # the allocation-free call FIRST: on the first round the engine is fresh -- no allocating ray cast has run on it,
+            # its grow-only ray / pose buffers do not exist yet -- so the call stands on the library's fixed array alone
             e.ray_cast_poses_noalloc(dT.data_ptr(), da.data_ptr(), db.data_ptr(), n, out.data_ptr())
             got = out.cpu().numpy()
+            want = e.ray_cast_poses(poses, a, b)
             assert np.array_equal(got[:n].view(np.uint32), want.view(np.uint32)), "n=%d: %d fractions differ" % (n, int((got[:n] != want).sum()))
             assert (got[n:] == -7.0).all()
             hits += int((want < 1).sum())

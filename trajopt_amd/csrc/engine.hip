@@ -1057,7 +1057,9 @@ static int launchTail(tohc_engine *e) {
     HIPCHK(hipStreamWaitEvent(ln.stream, e->tail_ranged, 0));
     HIPCHK(hipEventRecord(ev[7], ln.stream));
     if (!h.empty) {
-      const int Kr = std::max(h.a.rb.K, 1);   // LDS: one pair of gradient rows per group
+      // LDS: one pair of gradient rows per group -- only the lane-per-joint epilogue (fast_jac: K <= TOHC_FAST_JAC_MAXK, so at
+      // most 64 KB for groups of 4) touches them; the lane-per-column fall-back (wide K, mimic joints) asks for none
+      const size_t Kr = h.a.rb.fast_jac ? (size_t)std::max(h.a.rb.K, 1) : 0;
       if (e->group == 64) hipLaunchKernelGGL((k_finish<64>), dim3(256 * 2), dim3(256), (size_t)(256 / 64) * 2 * Kr * sizeof(double), ln.stream, h.a);
       else hipLaunchKernelGGL((k_finish<TOHC_FINISH_G>), dim3(256 * TOHC_FINISH_BLOCKS_PER_CU), dim3(256), (size_t)(256 / TOHC_FINISH_G) * 2 * Kr * sizeof(double), ln.stream, h.a);
     }
@@ -1986,13 +1988,15 @@ int tohc_ray_cast_poses_noalloc(tohc_engine *e, const double *d_obj_T, const dou
   const DynMap dm = dynMapPoses(e);
   // every word the kernels below read from the working buffer is written by the two kernels before them in this call:
   // nothing of an earlier call's contents is used, so nothing needs clearing
-  hipLaunchKernelGGL(k_dyn_children, dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, s, devScene(e), dm, d_obj_T, 1, e->d, xf, box);
+  if (nch > 0) hipLaunchKernelGGL(k_dyn_children, dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, s, devScene(e), dm, d_obj_T, 1, e->d, xf, box);
   hipLaunchKernelGGL(k_ray_prep, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, s, d_from, d_to, n_rays, rays,
-                     reinterpret_cast<unsigned int *>(d_closest_fraction));
+                     reinterpret_cast<unsigned int *>(d_closest_fraction));   // (presets every fraction to 1 = nothing hit)
   const size_t tot = (size_t)n_rays * nch;   // <= 65536 * 8192 tests: the grid below fits
-  RayArgs ra;
-  ra.sc = devScene(e); ra.dm = dm; ra.dynXf = xf; ra.rays = rays; ra.closest = reinterpret_cast<unsigned int *>(d_closest_fraction); ra.n_rays = n_rays;
-  hipLaunchKernelGGL(k_ray, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ra);
+  if (tot > 0) {
+    RayArgs ra;
+    ra.sc = devScene(e); ra.dm = dm; ra.dynXf = xf; ra.rays = rays; ra.closest = reinterpret_cast<unsigned int *>(d_closest_fraction); ra.n_rays = n_rays;
+    hipLaunchKernelGGL(k_ray, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ra);
+  }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s));
   return TOHC_OK;

@@ -400,7 +400,9 @@ bool createConvexHull(const std::vector<V3> &pts, std::vector<V3> &hullVerts) {
 }  // namespace
 
 extern "C" int tohc_shape_hull(const float *verts, int n_verts, const int32_t *tri, int n_tri, float *out, int cap) {
-  if (!verts || n_verts < 0 || n_tri < 0 || (n_tri > 0 && !tri) || (cap > 0 && !out)) return TOHC_E_INVALID;
+  // a mesh names at least one triangle (the reference asserts indices.size() >= 3, bullet_collision_checker.cpp:162): with
+  // none, a mesh of >= 50 vertices would take 42 support points over nothing and return HullLibrary's fall-back box
+  if (!verts || n_verts < 1 || n_tri < 1 || !tri || (cap > 0 && !out)) return TOHC_E_INVALID;
   for (int i = 0; i < 3 * n_tri; ++i)
     if (tri[i] < 0 || tri[i] >= n_verts) return TOHC_E_INVALID;
   std::vector<V3> hull;

@@ -120,7 +120,7 @@ def shape_hull(vertices, triangles):
     t = np.ascontiguousarray(triangles, np.int32).reshape(-1, 3)
     n = lib.tohc_shape_hull(_p(v, C.c_float), len(v), _p(t, C.c_int32), len(t), None, 0)
     if n < 0:
-        raise EngineError(n, "tohc_shape_hull: bad mesh (an index outside the vertex table?)")
+        raise EngineError(n, "tohc_shape_hull: bad mesh (no vertices, no triangles, or an index outside the vertex table)")
     out = np.zeros((n, 3), np.float32)
     lib.tohc_shape_hull(_p(v, C.c_float), len(v), _p(t, C.c_int32), len(t), _p(out, C.c_float), n)
     return out

@@ -2,6 +2,8 @@
 // libtrajopt_hipcc.so; there is no CPU path here: without the library / a GPU, tohc_create fails and the constructor throws.
 #include "hip_collision_checker.hpp"
 
+#include "rave_access.hpp"   // the robot's kinematic tree and grabbed links (stand-in here; openrave/rave_access.hpp upstream)
+
 #include <algorithm>
 #include <cassert>
 #include <cstdlib>
@@ -47,8 +49,8 @@ void HIPCollisionChecker::chk(int rc) const {
 }
 
 HIPCollisionChecker::HIPCollisionChecker(OR::EnvironmentBaseConstPtr env)
-    : CollisionChecker(env), m_e(NULL), m_contactDistance(.05), m_bound(NULL), m_fkRobot(NULL), m_upRobot(NULL), m_upAffine(0), m_fkStamp(~0ul),
-      m_prefetchMask(-1), m_prefetchHits(0), m_engineCalls(0) {
+    : CollisionChecker(env), m_e(NULL), m_contactDistance(.05), m_bound(NULL), m_upRobot(NULL), m_upAffine(0), m_prefetchMask(-1), m_prefetchHits(0),
+      m_engineCalls(0) {
   int dev = 0;
   if (const char* s = getenv("TRAJOPT_HIP_DEVICE")) dev = atoi(s);
   if (tohc_create(&m_e, dev) != TOHC_OK) throw std::runtime_error("HIPCollisionChecker: no MI355X / HIP runtime (the engine has no CPU fallback)");
@@ -74,7 +76,7 @@ void HIPCollisionChecker::Rebuild(const vector<OR::KinBodyPtr>& bodies) {
       const auto& geoms = link->GetGeometries();
       if (geoms.empty()) continue;   // CollisionObjectFromLink returns no object, :218
       objOff.push_back((int32_t)childShape.size()), objCnt.push_back((int32_t)geoms.size());
-      objCompound.push_back(!(geoms.size() == 1 && isIdentity(geoms[0].GetTransform())));   // :224
+      objCompound.push_back(!(geoms.size() == 1 && isIdentity(geoms[0]->GetTransform())));   // :224
       objGroup.push_back(body->IsRobot() ? RobotFilter : KinBodyFilter);                    // :538
       double t7[7];
       put7(link->GetTransform(), t7);
@@ -84,14 +86,14 @@ void HIPCollisionChecker::Rebuild(const vector<OR::KinBodyPtr>& bodies) {
       for (const auto& g : geoms) {   // createShapePrimitive, :134-212
         float p[4] = {0, 0, 0, 0};
         voff.push_back((int32_t)vx.size());
-        switch (g.GetType()) {
-          case OR::GT_Box: kind.push_back(TOHC_BOX), p[0] = (float)g.boxExtents.x, p[1] = (float)g.boxExtents.y, p[2] = (float)g.boxExtents.z; break;
-          case OR::GT_Sphere: kind.push_back(TOHC_SPHERE), p[0] = (float)g.radius; break;
-          case OR::GT_Cylinder: kind.push_back(TOHC_CYLZ), p[0] = (float)g.radius, p[1] = (float)(g.height / 2.); break;   // :153-158
+        switch (g->GetType()) {
+          case OR::GT_Box: kind.push_back(TOHC_BOX), p[0] = (float)g->GetBoxExtents().x, p[1] = (float)g->GetBoxExtents().y, p[2] = (float)g->GetBoxExtents().z; break;
+          case OR::GT_Sphere: kind.push_back(TOHC_SPHERE), p[0] = (float)g->GetSphereRadius(); break;
+          case OR::GT_Cylinder: kind.push_back(TOHC_CYLZ), p[0] = (float)g->GetCylinderRadius(), p[1] = (float)(g->GetCylinderHeight() / 2.); break;   // :153-158
           case OR::GT_TriMesh: {
             // :160-203: below 50 vertices the mesh's vertices are the hull's points, from 50 on btShapeHull's <= 42
             // support points (tohc_shape_hull restates btShapeHull::buildHull + HullLibrary)
-            const OR::TriMesh& mesh = g.GetCollisionMesh();
+            const OR::TriMesh& mesh = g->GetCollisionMesh();
             if (mesh.indices.size() < 3) throw std::runtime_error("HIPCollisionChecker: triangle mesh without triangles");   // assert, :162
             vector<float> mv;
             for (const Vector& v : mesh.vertices) mv.push_back((float)v.x), mv.push_back((float)v.y), mv.push_back((float)v.z);   // toBt, :166
@@ -109,13 +111,14 @@ void HIPCollisionChecker::Rebuild(const vector<OR::KinBodyPtr>& bodies) {
         vcnt.push_back((int32_t)vx.size() - voff.back());
         param.insert(param.end(), p, p + 4);
         childShape.push_back((int32_t)kind.size() - 1);
-        put7(g.GetTransform(), t7);
+        put7(g->GetTransform(), t7);
         childT.insert(childT.end(), t7, t7 + 7);
       }
     }
   }
   int n = (int)m_obj2link.size();
-  m_upRobot = NULL, m_fkRobot = NULL, m_fkStamp = ~0ul;
+  ++m_rebuilds;   // object numbers may have changed: whatever was derived from them (m_affectedObjs) is stale
+  m_upRobot = NULL;
   m_uploadedT = staticT;
   InvalidatePrefetch();
   m_allowed.assign((size_t)n * n, 1);   // SetLinkIndices, :606-614
@@ -160,8 +163,11 @@ void HIPCollisionChecker::UpdateFromRave() {   // UpdateBulletFromRave, :629-655
   // device and take the poses of everything that is not a robot link from the scene upload: refresh it when one moved.
   std::set<const KinBody*> carried;   // grabbed bodies move with their robot: their poses come from FK, not from the upload
   for (const OR::KinBodyPtr& b : bodies)
-    if (const RobotBase* rb = dynamic_cast<const RobotBase*>(b.get()))
-      for (const RobotBase::Grabbed& g : rb->GetGrabbedInfo()) carried.insert(g.body.get());
+    if (const RobotBase* rb = dynamic_cast<const RobotBase*>(b.get())) {
+      vector<OR::KinBodyPtr> grabbed;
+      rb->GetGrabbed(grabbed);
+      for (const OR::KinBodyPtr& g : grabbed) carried.insert(g.get());
+    }
   for (size_t o = 0; o < m_obj2link.size(); ++o) {
     if (m_obj2link[o]->GetParent()->IsRobot() || carried.count(m_obj2link[o]->GetParent())) continue;
     double t7[7];
@@ -217,47 +223,84 @@ bool HIPCollisionChecker::RobotUploadIsCurrent(RobotAndDOF& rad) const {
   return true;
 }
 
-// what of the robot's grabbed bodies the upload depends on: (body, grabbing link, relative pose) of each
+// what of the robot's grabbed bodies the upload depends on: (link, grabbing link, relative pose) of each grabbed link
 vector<double> HIPCollisionChecker::GrabSignature(const RobotBase& r) const {
   vector<double> sig;
-  for (const RobotBase::Grabbed& g : r.GetGrabbedInfo()) {
+  vector<rave_access::GrabbedLink> gl;
+  rave_access::GrabbedLinks(r, gl);
+  for (const rave_access::GrabbedLink& g : gl) {
     double t7[7];
-    put7(g.rel, t7);
-    sig.push_back((double)(uintptr_t)g.body.get()), sig.push_back(g.link);
+    put7(g.poseInGrabber, t7);
+    sig.push_back((double)(uintptr_t)g.link), sig.push_back((double)(uintptr_t)g.grabber);
     sig.insert(sig.end(), t7, t7 + 7);
   }
   return sig;
 }
 
+// ---- affine DOFs <-> body transform (RaveGetTransformFromAffineDOFValues / RaveGetAffineDOFValuesFromTransform, as
+// RobotAndDOF uses them, configuration_space.cpp:12-35) ----------------------------------------------------------------
+static Transform affineTransform(const double* v, int affinedofs, const Vector& axis) {
+  Transform T;
+  if (affinedofs & OR::DOF_X) T.trans.x = *v++;
+  if (affinedofs & OR::DOF_Y) T.trans.y = *v++;
+  if (affinedofs & OR::DOF_Z) T.trans.z = *v++;
+  if (affinedofs & OR::DOF_RotationAxis) {
+    const double a = *v++, s = sin(a / 2);
+    T.rot = Vector(cos(a / 2), axis.x * s, axis.y * s, axis.z * s);
+  }
+  return T;
+}
+static double poseDistance(const Transform& a, const Transform& b) {   // max |difference| of translation and (sign-free) quaternion
+  double d = std::max(fabs(a.trans.x - b.trans.x), std::max(fabs(a.trans.y - b.trans.y), fabs(a.trans.z - b.trans.z)));
+  const double sgn = (a.rot.x * b.rot.x + a.rot.y * b.rot.y + a.rot.z * b.rot.z + a.rot.w * b.rot.w) < 0 ? -1 : 1;
+  d = std::max(d, std::max(std::max(fabs(a.rot.x - sgn * b.rot.x), fabs(a.rot.y - sgn * b.rot.y)), std::max(fabs(a.rot.z - sgn * b.rot.z), fabs(a.rot.w - sgn * b.rot.w))));
+  return d;
+}
+// Does the configuration's DOF vector describe the robot's state?  Without affine DOFs always (the body transform is part
+// of the upload); with them only while the body transform is one the affine DOFs can express -- IgnoreZeroStateSelfCollisions
+// lifts the body to z = 10 by SetTransform (collision_checker.cpp:47), which DOF_X | DOF_Y | DOF_RotationAxis cannot.
+bool HIPCollisionChecker::StateIsRepresentable(RobotAndDOF& rad) const {
+  if (rad.affinedofs == 0) return true;
+  const DblVec q = rad.GetDOFValues();
+  return poseDistance(affineTransform(q.data() + rad.joint_inds.size(), rad.affinedofs, rad.rotationaxis), rad.robot->GetTransform()) <= 1e-12;
+}
+
 void HIPCollisionChecker::UploadRobot(RobotAndDOF& rad) {
   if (RobotUploadIsCurrent(rad)) return;
   RobotBase* r = rad.robot.get();
-  const vector<RobotBase::Joint>& J = r->GetJoints();
-  const int nr = (int)J.size();
-  // Grabbed bodies (configuration_space.cpp:120-131): every link with geometry of a grabbed body becomes a FIXED link
+  vector<rave_access::TreeNode> nodes;
+  rave_access::FlattenRobot(*r, nodes);
+  const int nr = (int)nodes.size();
+  std::map<const KinBody::Link*, int> nodeOf;
+  for (int i = 0; i < nr; ++i)
+    if (nodes[i].link) nodeOf[nodes[i].link] = i;
+  // Grabbed bodies (configuration_space.cpp:120-131): every link with geometry of a grabbed body becomes a FIXED node
   // hanging off the grabbing link, marked TOHC_DOF_GRABBED -- a query link whatever moves it, with the grabber's Jacobian
-  struct Extra { int parent; Transform origin; const KinBody::Link* link; };
-  vector<Extra> extra;
-  for (const RobotBase::Grabbed& g : r->GetGrabbedInfo())
-    for (const KinBody::LinkPtr& l : g.body->GetLinks())
-      if (!l->GetGeometries().empty() && m_link2obj.count(l.get())) extra.push_back(Extra{g.link, g.rel * l->m_rel, l.get()});
+  vector<rave_access::GrabbedLink> grabbed, extra;
+  rave_access::GrabbedLinks(*r, grabbed);
+  for (const rave_access::GrabbedLink& g : grabbed)
+    if (!g.link->GetGeometries().empty() && m_link2obj.count(g.link) && nodeOf.count(g.grabber)) extra.push_back(g);
   int n = nr + (int)extra.size();
   vector<int32_t> parent(n), jtype(n), dof(n), linkObj(n);
   vector<double> origin(7 * n), axis(3 * n), mult(n), offs(n);
+  m_upNodeLinks.assign(n, (const KinBody::Link*)NULL);
   for (int k = 0; k < (int)extra.size(); ++k) {
     const int i = nr + k;
-    parent[i] = extra[k].parent, jtype[i] = TOHC_J_FIXED, dof[i] = TOHC_DOF_GRABBED, mult[i] = 1, offs[i] = 0;
-    put7(extra[k].origin, &origin[7 * i]);
+    parent[i] = nodeOf.at(extra[k].grabber), jtype[i] = TOHC_J_FIXED, dof[i] = TOHC_DOF_GRABBED, mult[i] = 1, offs[i] = 0;
+    put7(extra[k].poseInGrabber, &origin[7 * i]);
     axis[3 * i] = 0, axis[3 * i + 1] = 0, axis[3 * i + 2] = 1;
     linkObj[i] = m_link2obj.at(extra[k].link);
+    m_upNodeLinks[i] = extra[k].link;
   }
   for (int i = 0; i < nr; ++i) {
-    parent[i] = J[i].parent, jtype[i] = J[i].type, dof[i] = J[i].dof, mult[i] = J[i].mult, offs[i] = J[i].offs;
-    put7(J[i].origin, &origin[7 * i]);
-    double l = sqrt(J[i].axis.x * J[i].axis.x + J[i].axis.y * J[i].axis.y + J[i].axis.z * J[i].axis.z);
-    axis[3 * i] = J[i].axis.x / l, axis[3 * i + 1] = J[i].axis.y / l, axis[3 * i + 2] = J[i].axis.z / l;
-    auto it = m_link2obj.find(r->GetLinks()[i].get());
+    const rave_access::TreeNode& J = nodes[i];
+    parent[i] = J.parent, jtype[i] = J.type, dof[i] = J.dof, mult[i] = J.mult, offs[i] = J.offs;
+    put7(J.origin, &origin[7 * i]);
+    double l = sqrt(J.axis.x * J.axis.x + J.axis.y * J.axis.y + J.axis.z * J.axis.z);
+    axis[3 * i] = J.axis.x / l, axis[3 * i + 1] = J.axis.y / l, axis[3 * i + 2] = J.axis.z / l;
+    auto it = J.link ? m_link2obj.find(J.link) : m_link2obj.end();
     linkObj[i] = it == m_link2obj.end() ? -1 : it->second;
+    m_upNodeLinks[i] = J.link;
   }
   DblVec q = r->GetDOFValues();
   double base[7], rot[3] = {rad.rotationaxis.x, rad.rotationaxis.y, rad.rotationaxis.z};
@@ -268,19 +311,60 @@ void HIPCollisionChecker::UploadRobot(RobotAndDOF& rad) {
                         (int)q.size(), q.empty() ? &qdummy : q.data(), base, (int)ji.size(), ji.data(), rad.affinedofs, rot));
   m_upRobot = r, m_upJointInds = rad.joint_inds, m_upAffine = rad.affinedofs, m_upRotAxis = rad.rotationaxis, m_upQ = q, m_upBase = r->GetTransform();
   m_upGrab = GrabSignature(*r), m_upLinks = n;
+  CheckDeviceFK(rad);
+}
+
+// The FK guard.  The linearizing queries run FK on the DEVICE, on the tree rave_access handed over; the explicit-pose
+// queries take link->GetTransform(), the host's FK (OpenRAVE's).  Contacts and gradients are only meaningful if the two
+// agree, and nothing in the reference pins the conventions (OpenRAVE is an external dependency: SURVEY.md 8c), so every
+// upload is checked at the robot's current state: each node that stands for a link, run through tohc_forward_kinematics,
+// must land on that link's GetTransform() -- relative to the base link always, absolutely whenever the DOF vector can
+// express the body transform.  A wrong joint convention then fails here, at bind time, instead of bending gradients.
+void HIPCollisionChecker::CheckDeviceFK(RobotAndDOF& rad) {
+  const double tol = 1e-9;
+  const bool absolute = StateIsRepresentable(rad);
+  DblVec q = rad.GetDOFValues();
+  if (!absolute) std::fill(q.begin() + rad.joint_inds.size(), q.end(), 0.0);   // (any base will do for the relative check)
+  vector<double> nodeT(7 * (size_t)m_upLinks);
+  chk(tohc_forward_kinematics(m_e, q.data(), 1, nodeT.data()));
+  ++m_engineCalls;
+  int ref = -1;
+  for (int i = 0; i < m_upLinks && ref < 0; ++i)
+    if (m_upNodeLinks[i]) ref = i;
+  if (ref < 0) return;
+  const Transform devRefInv = get7(&nodeT[7 * ref]).inverse(), hostRefInv = m_upNodeLinks[ref]->GetTransform().inverse();
+  for (int i = 0; i < m_upLinks; ++i) {
+    if (!m_upNodeLinks[i]) continue;
+    const Transform dev = get7(&nodeT[7 * i]), host = m_upNodeLinks[i]->GetTransform();
+    const double dr = poseDistance(devRefInv * dev, hostRefInv * host), da = absolute ? poseDistance(dev, host) : 0;
+    if (!(dr <= tol) || !(da <= tol)) {
+      m_upRobot = NULL;   // this upload must not be used
+      char msg[512];
+      snprintf(msg, sizeof msg, "HIPCollisionChecker: the engine's forward kinematics disagrees with link '%s' (GetTransform) by %.3g relative to the base link"
+               "%s: the kinematic tree handed to tohc_upload_robot does not describe this robot", m_upNodeLinks[i]->GetName().c_str(), dr,
+               absolute ? (", " + std::to_string(da) + " absolutely").c_str() : "");
+      throw std::runtime_error(msg);
+    }
+  }
 }
 
 void HIPCollisionChecker::BindConfiguration(Configuration& c) {
   RobotAndDOF* rad = dynamic_cast<RobotAndDOF*>(&c);
   if (!rad) throw std::runtime_error("HIPCollisionChecker: only RobotAndDOF configurations are supported");
   UpdateFromRave();
+  // The kept binding stands while the configuration is the same AND what m_affectedObjs was derived from is: the object
+  // numbering (a Rebuild renumbers) and the robot's grab set (GetAffectedLinks lists grabbed links, configuration_space.cpp:
+  // 120-131) -- a Grab / Release between two evaluators on the same robot and joints must refresh the list, or LinksVsAll /
+  // CastVsAll would take the explicit-pose route, whose contacts carry no linearization.
+  const vector<double> grabNow = GrabSignature(*rad->robot);
   if (m_boundKeep.get() && m_bound == m_boundKeep.get() && m_bound->robot == rad->robot && m_bound->joint_inds == rad->joint_inds &&
       m_bound->affinedofs == rad->affinedofs && m_bound->rotationaxis.x == rad->rotationaxis.x && m_bound->rotationaxis.y == rad->rotationaxis.y &&
-      m_bound->rotationaxis.z == rad->rotationaxis.z)
+      m_bound->rotationaxis.z == rad->rotationaxis.z && m_boundRebuilds == m_rebuilds && m_boundGrab == grabNow)
     return;
   // keep our own copy: evaluators come and go, the checker lives with the environment
   m_boundKeep.reset(new RobotAndDOF(rad->robot, rad->joint_inds, rad->affinedofs, rad->rotationaxis));
   m_bound = m_boundKeep.get();
+  m_boundRebuilds = m_rebuilds, m_boundGrab = grabNow;
   vector<KinBody::LinkPtr> links;
   vector<int> inds;
   m_bound->GetAffectedLinks(links, true, inds);
@@ -300,35 +384,7 @@ bool HIPCollisionChecker::IsAffectedSet(const vector<KinBody::LinkPtr>& links) c
   return ids == m_affectedObjs;
 }
 
-void HIPCollisionChecker::UpdateRobotLinkTransforms() {
-  for (const OR::KinBodyPtr& body : m_prevbodies) {
-    RobotBase* r = dynamic_cast<RobotBase*>(body.get());
-    if (!r) continue;
-    const vector<RobotBase::Joint>& J = r->GetJoints();
-    if (r->GetDOF() == 0) {   // a rigid robot (boxbot): compose on the host, nothing for the FK kernel to do
-      for (size_t i = 0; i < J.size(); ++i)
-        r->GetLinks()[i]->m_T = (J[i].parent < 0 ? r->GetTransform() : r->GetLinks()[J[i].parent]->m_T) * J[i].origin;
-      for (const RobotBase::Grabbed& g : r->GetGrabbedInfo()) g.body->SetTransform(r->GetLinks()[g.link]->m_T * g.rel);
-      continue;
-    }
-    if (m_fkRobot == r && m_fkStamp == r->GetStamp()) continue;
-    // all joints active, base = the body transform: the engine's FK kernel run on the robot's current state
-    IntVec all(r->GetDOF());
-    for (int j = 0; j < r->GetDOF(); ++j) all[j] = j;
-    RobotAndDOF full(std::dynamic_pointer_cast<RobotBase>(body), all, 0);
-    UploadRobot(full);
-    vector<double> linkT(7 * (size_t)m_upLinks);   // the robot's links, then the grabbed bodies' (UploadRobot)
-    chk(tohc_forward_kinematics(m_e, r->GetDOFValues().data(), 1, linkT.data()));
-    ++m_engineCalls;
-    for (size_t i = 0; i < J.size(); ++i) r->GetLinks()[i]->m_T = get7(&linkT[7 * i]);
-    for (const RobotBase::Grabbed& g : r->GetGrabbedInfo())   // OpenRAVE carries grabbed bodies along with the grabbing link
-      g.body->SetTransform(r->GetLinks()[g.link]->m_T * g.rel);
-    m_fkRobot = r, m_fkStamp = r->GetStamp();
-  }
-}
-
-vector<double> HIPCollisionChecker::CurrentPoses() {
-  UpdateRobotLinkTransforms();
+vector<double> HIPCollisionChecker::CurrentPoses() {   // UpdateBulletFromRave's pose loop, :648-653
   vector<double> T(7 * m_obj2link.size());
   for (size_t o = 0; o < m_obj2link.size(); ++o) put7(m_obj2link[o]->GetTransform(), &T[7 * o]);
   return T;
@@ -350,11 +406,23 @@ Collision HIPCollisionChecker::ToCollision(const tohc_record& r, const double* g
 // ---- queries -------------------------------------------------------------------------------------------------------
 const HIPCollisionChecker::Prefetched* HIPCollisionChecker::FindPrefetched(const DblVec& q0, const DblVec* q1, short filterMask) const {
   if (m_prefetch.empty() || (!q1 && filterMask != m_prefetchMask)) return NULL;
-  size_t key = hashRange(q0, q1 ? 1 : 0);
-  auto range = m_prefetchIndex.equal_range(key);
-  for (auto it = range.first; it != range.second; ++it) {
-    const Prefetched& p = m_prefetch[it->second];
-    if (p.q0 == q0 && (q1 ? p.q1 == *q1 : p.q1.empty())) return &p;
+  if (q1) {   // CastVsAll is handed its two DOF vectors: exact look-up
+    size_t key = hashRange(q0, 1);
+    auto range = m_prefetchIndex.equal_range(key);
+    for (auto it = range.first; it != range.second; ++it) {
+      const Prefetched& p = m_prefetch[it->second];
+      if (p.q0 == q0 && p.q1 == *q1) return &p;
+    }
+    return NULL;
+  }
+  // LinksVsAll is handed nothing: its DOF vector is read back from the robot (RobotAndDOF::GetDOFValues), and an affine
+  // rotation angle does not survive angle -> quaternion -> angle bit for bit.  So: the prefetched timestep within 1e-12 of
+  // the robot's state (far below any step the optimiser takes; the contacts handed out are those AT the prefetched vector).
+  for (const Prefetched& p : m_prefetch) {
+    if (!p.q1.empty() || p.q0.size() != q0.size()) continue;
+    double d = 0;
+    for (size_t i = 0; i < q0.size() && d <= 1e-12; ++i) d = std::max(d, fabs(p.q0[i] - q0[i]));
+    if (d <= 1e-12) return &p;
   }
   return NULL;
 }
@@ -363,11 +431,8 @@ void HIPCollisionChecker::LinksVsAll(const vector<KinBody::LinkPtr>& links, vect
   UpdateFromRave();
   if (m_obj2link.empty()) return;
   // The linearizing route runs FK on the device from the bound configuration's DOF vector, so it only applies while
-  // that vector describes the robot's state: with affine DOFs, while the body transform is the one last set through a
-  // RobotAndDOF (IgnoreZeroStateSelfCollisions lifts the body to z = 10 by SetTransform: explicit-pose route then).
-  DblVec aff;
-  const bool representable = m_bound && (m_bound->affinedofs == 0 || m_bound->robot->GetCachedAffineDOFValues(m_bound->affinedofs, m_bound->rotationaxis, aff));
-  if (representable && IsAffectedSet(links)) {
+  // that vector describes the robot's state (StateIsRepresentable; else the explicit-pose route below).
+  if (m_bound && IsAffectedSet(links) && StateIsRepresentable(*m_bound)) {
     // the query the collision terms make (collision_terms.cpp:118-122): contacts AND their linearization
     DblVec q = m_bound->GetDOFValues();
     if (const Prefetched* p = FindPrefetched(q, NULL, filterMask)) {
@@ -455,7 +520,6 @@ void HIPCollisionChecker::CastVsAll(Configuration& rad, const vector<KinBody::Li
   }
   if (query.empty()) return;
   rad.SetDOFValues(endjoints);
-  UpdateRobotLinkTransforms();
   vector<double> T1(7 * query.size());
   for (size_t i = 0; i < qlinks.size(); ++i) put7(qlinks[i]->GetTransform(), &T1[7 * i]);
   rad.SetDOFValues(startjoints);
@@ -471,7 +535,8 @@ void HIPCollisionChecker::CastVsAll(Configuration& rad, const vector<KinBody::Li
 vector<float> HIPCollisionChecker::RayCastCollisions(const vector<double>& points1, const vector<double>& points2) {
   if (points1.size() != points2.size() || points1.size() % 3 != 0) throw std::runtime_error("RayCastCollisions: point arrays must hold the same number of xyz triples");
   vector<float> closest(points1.size() / 3, 1.0f);
-  if (closest.empty()) return closest;
+  UpdateFromRave();   // :356 -- bodies added, removed or moved since the last call
+  if (closest.empty() || m_obj2link.empty()) return closest;   // an empty world: nothing to hit
   vector<double> T = CurrentPoses();
   chk(tohc_ray_cast_poses(m_e, T.data(), points1.data(), points2.data(), (int)closest.size(), closest.data()));
   ++m_engineCalls;
@@ -535,7 +600,7 @@ void HIPCollisionChecker::PrefetchTrajectory(Configuration& rad, const TrajArray
     bool isCast = r[i].cctype != CCType_None;   // CastCollisionCollector always sets Time0 / Time1 / Between (:909-967)
     m_prefetch[(isCast ? nd : 0) + r[i].t].collisions.push_back(ToCollision(r[i], g + (size_t)i * 2 * K, K));
   }
-  for (int i = 0; i < nd + nc; ++i) m_prefetchIndex.insert(std::make_pair(hashRange(m_prefetch[i].q0, m_prefetch[i].q1.empty() ? 0 : 1), i));
+  for (int i = nd; i < nd + nc; ++i) m_prefetchIndex.insert(std::make_pair(hashRange(m_prefetch[i].q0, 1), i));   // (cast pairs; discrete entries are scanned)
 }
 
 }  // namespace trajopt

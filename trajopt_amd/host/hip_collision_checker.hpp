@@ -50,9 +50,8 @@ class HIPCollisionChecker : public CollisionChecker {
       the cast contacts of every (t, t+1) pair, with their linearizations.  Later LinksVsAll / CastVsAll calls at those
       DOF vectors are answered from this slab.  Invalidated by any change of the world, d, or the exclusions. */
   void PrefetchTrajectory(Configuration& rad, const TrajArray& traj, bool discrete, bool cast, short filterMask = -1);
-  /** Robot link poses come from the engine's FK kernel (OpenRAVE's FK in the reference). */
-  void UpdateRobotLinkTransforms();
   tohc_engine* GetEngine() { return m_e; }
+  bool HasPrefetch() const { return !m_prefetch.empty(); }   // false again after anything invalidated it (world, d, exclusions)
   long NumPrefetchHits() const { return m_prefetchHits; }
   long NumEngineCalls() const { return m_engineCalls; }
 
@@ -67,6 +66,8 @@ class HIPCollisionChecker : public CollisionChecker {
   void Rebuild(const vector<OR::KinBodyPtr>& bodies);   // AddKinBody / CollisionObjectFromLink / createShapePrimitive, :134-255,535-561
   void UpdateAllowedCollisionMatrix();                  // :616-627
   void UploadRobot(RobotAndDOF& rad);
+  void CheckDeviceFK(RobotAndDOF& rad);                 // the FK guard: device FK of the uploaded tree == link->GetTransform()
+  bool StateIsRepresentable(RobotAndDOF& rad) const;    // the DOF vector describes the robot's state (affine DOFs vs body transform)
   vector<double> GrabSignature(const OR::RobotBase& r) const;
   bool RobotUploadIsCurrent(RobotAndDOF& rad) const;
   vector<double> CurrentPoses();    // [n_objects][7]
@@ -86,16 +87,17 @@ class HIPCollisionChecker : public CollisionChecker {
   // robot binding
   RobotAndDOF* m_bound;
   std::shared_ptr<RobotAndDOF> m_boundKeep;
-  OR::RobotBase* m_fkRobot;
   OR::RobotBase* m_upRobot;
   IntVec m_upJointInds;
   int m_upAffine;
   OR::Vector m_upRotAxis;
   DblVec m_upQ, m_upGrab;
-  int m_upLinks = 0;                // links in the upload: the robot's, then one per grabbed link with geometry
+  int m_upLinks = 0;                // nodes of the uploaded tree: the robot's, then one per grabbed link with geometry
+  vector<const KinBody::Link*> m_upNodeLinks;   // the link each node stands for (NULL: an intermediate joint frame)
   OR::Transform m_upBase;
   vector<int> m_affectedObjs;       // object ids of the bound configuration's affected links with geometry
-  unsigned long m_fkStamp;
+  unsigned long m_rebuilds = 0, m_boundRebuilds = ~0ul;   // scene uploads so far / the one m_affectedObjs was derived under
+  DblVec m_boundGrab;               // the robot's grab set m_affectedObjs was derived under (GrabSignature)
   // prefetch
   vector<Prefetched> m_prefetch;
   std::unordered_multimap<size_t, int> m_prefetchIndex;

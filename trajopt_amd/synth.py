@@ -334,3 +334,22 @@ def config_benchmark_scene(name="kitchen_counter"):
     add_ref_scene(s, name)
     s.finalize(); rb.finalize()
     return s, rb, static_poses(s), 0.09
+
+
+def config_ref_problem(name="arm_around_table"):
+    """Configs 1 / 2 as the reference ships them: data/arm_around_table.json (T = 10) / arm_around_table_continuous.json
+    (T = 6) -- the numbers of tests/golden/ref_problems.json, made by tests/golden/make_problems.py -- with the PR2-like right
+    arm (the PR2 model itself is OpenRAVE's) over the table of data/table.xml: a static link at identity whose one box
+    geometry sits at its own translation, i.e. a compound of one child (bullet_collision_checker.cpp:224-250).
+    -> scene, robot, static poses, d (= dist_pen + 0.04), the init trajectory [T][7], the problem's dict."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "ref_problems.json")) as f:
+        j = json.load(f)
+    p, tb = j[name], j["table"]
+    s = M.Scene()
+    rb = pr2_like(s, seed=0, active=p["manip"])
+    s.add_object([(s.add_box(*tb["extents"]), T7(tb["translation"]))], M.GROUP_KINBODY, name="table_link")
+    s.finalize(); rb.finalize()
+    return s, rb, static_poses(s), float(p["contact_distance"]), np.array(p["init_traj"], float), p
