@@ -19,6 +19,7 @@
 
 #include "collision_prefetch_cost.hpp"
 #include "hip_collision_checker.hpp"
+#include "rave_access.hpp"   // (the stand-in's: TestTamper)
 
 using namespace OR;
 using namespace trajopt;
@@ -507,9 +508,11 @@ static void test_linearize(const string& in, const string& out) {
     EXPECT_EQ(A.values.size(), C.values.size());
     for (size_t i = 0; i < A.values.size() && i < C.values.size(); ++i) EXPECT_TRUE(A.values[i] == C.values[i]);
   }
-  // the linearization is exact at x: every hinge row evaluates to dist_pen - distance there
+  // the linearization is exact at x: every hinge row evaluates to dist_pen - distance there (cast rows: to the 6e-8 by which
+  // the reference's float `1 - time` and `time` miss summing to one)
   for (size_t i = 0; i < B.hinges.size(); ++i)
-    for (size_t h = 0; h < B.hinges[i].size(); ++h) EXPECT_NEAR(B.hinges[i][h].at(x), W.dist_pen - B.contacts[i][h].distance, 1e-9);
+    for (size_t h = 0; h < B.hinges[i].size(); ++h)
+      EXPECT_NEAR(B.hinges[i][h].at(x), W.dist_pen - B.contacts[i][h].distance, 1e-9 + ((int)i >= T ? 1.2e-7 * fabs(B.contacts[i][h].distance) : 0));
 
   FILE* f = fopen(out.c_str(), "w");
   if (!f) throw std::runtime_error("cannot write " + out);
@@ -565,9 +568,9 @@ static KinBodyPtr makeSlab(const string& name, const Vector& half, const Vector&
 }
 
 // The FK guard (HIPCollisionChecker::CheckDeviceFK): the tree handed to tohc_upload_robot, run through the engine's FK
-// kernel, must reproduce every link->GetTransform().  Here the host's robot is made to disagree with the tree the checker
-// reads -- one joint origin is moved AFTER the host placed its links (the state stamp is not bumped, as a wrong convention
-// in rave_access would look) -- and the bind must throw; with the robot put right again it must not.
+// kernel, must reproduce every link->GetTransform().  Here the checker is handed a tree that is not the robot's (the
+// stand-in's TestTamper hook: what a wrong convention in an implementation of rave_access.hpp would look like) and the
+// bind must throw, naming the link; with the true tree it must not.
 static void test_fk_guard() {
   EnvironmentBasePtr env(new EnvironmentBase);
   RobotBasePtr arm = makeArm3();
@@ -582,43 +585,34 @@ static void test_fk_guard() {
   vector<Collision> ok;
   checker->CastVsAll(*rad, links, q0, q1, ok);   // binds, uploads, passes the guard
   EXPECT_TRUE(!ok.empty() && (int)ok[0].grad0.size() == 3);
-  // (i) a tree that is not the robot's: joint 2 sits 5 mm from where the host's FK has it
-  RobotBase::Joint& j2 = const_cast<RobotBase::Joint&>(arm->GetJoints()[2]);
-  const Transform good = j2.origin;
-  j2.origin.trans.x += 0.005;
-  RobotAndDOFPtr rad2(new RobotAndDOF(arm, IntVec{0, 1}, 0, Vector(0, 0, 1), env));   // another active set: a new upload
-  vector<KinBody::LinkPtr> links2;
-  rad2->GetAffectedLinks(links2, true, inds);
-  bool threw = false;
-  try {
-    vector<Collision> c;
-    checker->CastVsAll(*rad2, links2, DblVec{0.2, 0.3}, DblVec{0.25, 0.35}, c);
-  } catch (const std::runtime_error& e) {
-    threw = string(e.what()).find("forward kinematics disagrees") != string::npos && string(e.what()).find("arm2") != string::npos;
-    if (!threw) printf("unexpected exception: %s\n", e.what());
-  }
-  EXPECT_TRUE(threw);
-  // (ii) put right again: the same bind goes through, and answers like the first one did for the shared pair of columns
-  j2.origin = good;
-  vector<Collision> again;
-  checker->CastVsAll(*rad2, links2, DblVec{0.2, 0.3}, DblVec{0.25, 0.35}, again);
-  EXPECT_TRUE(!again.empty() && (int)again[0].grad0.size() == 2);
+  auto bindThrows = [&](const IntVec& active, const DblVec& a, const DblVec& b, const char* names) {
+    RobotAndDOFPtr r2(new RobotAndDOF(arm, active, 0, Vector(0, 0, 1), env));   // another active set: a new upload
+    vector<KinBody::LinkPtr> l2;
+    r2->GetAffectedLinks(l2, true, inds);
+    try {
+      vector<Collision> c;
+      checker->CastVsAll(*r2, l2, a, b, c);
+    } catch (const std::runtime_error& e) {
+      const bool ours = string(e.what()).find("forward kinematics disagrees") != string::npos && (!names || string(e.what()).find(names) != string::npos);
+      if (!ours) printf("unexpected exception: %s\n", e.what());
+      return ours;
+    }
+    return false;
+  };
+  // (i) joint 2 sits 5 mm from where the host's FK has it
+  rave_access::TestTamper() = [](vector<rave_access::TreeNode>& n) { n[2].origin.trans.x += 0.005; };
+  EXPECT_TRUE(bindThrows(IntVec{0, 1}, DblVec{0.2, 0.3}, DblVec{0.25, 0.35}, "arm2"));
+  // (ii) the true tree again: the same bind goes through
+  rave_access::TestTamper() = nullptr;
+  EXPECT_TRUE(!bindThrows(IntVec{0, 1}, DblVec{0.2, 0.3}, DblVec{0.25, 0.35}, NULL));
   // (iii) a mirrored axis convention (the classic): joint 1 about -y instead of +y
-  j2.origin = good;
-  RobotBase::Joint& j1 = const_cast<RobotBase::Joint&>(arm->GetJoints()[1]);
-  j1.axis = Vector(0, -1, 0);
-  RobotAndDOFPtr rad3(new RobotAndDOF(arm, IntVec{1, 2}, 0, Vector(0, 0, 1), env));
-  vector<KinBody::LinkPtr> links3;
-  rad3->GetAffectedLinks(links3, true, inds);
-  threw = false;
-  try {
-    vector<Collision> c;
-    checker->CastVsAll(*rad3, links3, DblVec{0.3, -0.4}, DblVec{0.35, -0.3}, c);
-  } catch (const std::runtime_error& e) {
-    threw = string(e.what()).find("forward kinematics disagrees") != string::npos;
-  }
-  EXPECT_TRUE(threw);
-  j1.axis = Vector(0, 1, 0);
+  rave_access::TestTamper() = [](vector<rave_access::TreeNode>& n) { n[1].axis = Vector(0, -1, 0); };
+  EXPECT_TRUE(bindThrows(IntVec{1, 2}, DblVec{0.3, -0.4}, DblVec{0.35, -0.3}, "arm1"));
+  // (iv) 1e-7 rad of joint offset: above the 1e-9 tolerance at a 0.3 m lever
+  rave_access::TestTamper() = [](vector<rave_access::TreeNode>& n) { n[0].offs += 1e-7; };
+  EXPECT_TRUE(bindThrows(IntVec{0, 2}, DblVec{0.2, -0.4}, DblVec{0.25, -0.3}, NULL));
+  rave_access::TestTamper() = nullptr;
+  EXPECT_TRUE(!bindThrows(IntVec{0, 2}, DblVec{0.2, -0.4}, DblVec{0.25, -0.3}, NULL));
 }
 
 // bind + LinksVsAll, then robot->Grab, then a NEW evaluator on the same robot and joints: the affected-link list

@@ -8,6 +8,7 @@
 // include path of the build.  UploadRobot checks whatever implementation it got against link->GetTransform() (the FK
 // guard), so a tree that does not reproduce the host's FK is refused at bind time.
 #pragma once
+#include <functional>
 #include <vector>
 
 #include "rave_shim.hpp"
@@ -26,6 +27,13 @@ struct TreeNode {
   const OR::KinBody::Link* link;    // the link whose frame this node is (NULL: an intermediate joint frame)
 };
 
+// (stand-in only) a hook for tests/cpp/host_unit fk_guard: lets a test hand the checker a tree that is NOT the robot's, the
+// way a wrong convention in an implementation of this header would
+inline std::function<void(std::vector<TreeNode>&)>& TestTamper() {
+  static std::function<void(std::vector<TreeNode>&)> f;
+  return f;
+}
+
 // The robot's kinematic tree.  Stand-in: one node per link, as RobotBase stores it.
 inline void FlattenRobot(const OR::RobotBase& r, std::vector<TreeNode>& nodes) {
   const std::vector<OR::RobotBase::Joint>& J = r.GetJoints();
@@ -35,6 +43,7 @@ inline void FlattenRobot(const OR::RobotBase& r, std::vector<TreeNode>& nodes) {
     n.parent = J[i].parent, n.type = (int)J[i].type, n.origin = J[i].origin, n.axis = J[i].axis, n.dof = J[i].dof, n.mult = J[i].mult, n.offs = J[i].offs;
     n.link = r.GetLinks()[i].get();
   }
+  if (TestTamper()) TestTamper()(nodes);
 }
 
 struct GrabbedLink {

@@ -40,10 +40,17 @@ def test_multistart_share_at_size_vs_oracle(built):
     assert disc.any() and (~disc).any()
     assert (np.diff(rec["problem"]) >= 0).all()                                         # canonical order
     key = np.stack([rec["problem"], rec["t"], (~disc).astype(np.int32), rec["idA"], rec["childA"], rec["idB"], rec["childB"]], 1)
-    assert len(np.unique(key, axis=0)) == len(key)                                      # one contact per child pair and pass
+    # one contact per child pair and pass -- except that a robot-robot pair is reported from each of its two query links
+    # (m_filterMask = -1 and the loop is over query links): exact duplicates, never more than two, discrete only
+    uk, first, cnt = np.unique(key, axis=0, return_index=True, return_counts=True)
+    grp = np.asarray(s.arrays["obj_group"])
+    assert cnt.max() <= 2
+    dup = rec[first[cnt == 2]]
+    assert (dup["cctype"] == 0).all() and (grp[dup["idA"]] & grp[dup["idB"]] & M.GROUP_ROBOT).all()
+    nxt = rec[first[cnt == 2] + 1]                      # (canonical order puts the twin right behind)
+    assert all(np.array_equal(dup[f], nxt[f]) for f in ("dist", "n", "ptA", "ptB", "const0"))
     assert (rec["dist"] <= np.float32(d)).all() and np.allclose(np.linalg.norm(rec["n"], axis=1), 1, atol=1e-5)
     assert (rec["t"][disc] < T).all() and (rec["t"][~disc] < T - 1).all()
-    grp = np.asarray(s.arrays["obj_group"])
     assert (grp[rec["idA"][~disc]] & M.GROUP_KINBODY).all() and (grp[rec["idB"][~disc]] & M.GROUP_ROBOT).all()   # cast: B is the swept link (bcc:913-917)
     q0 = dofs[rec["problem"], rec["t"]]
     q1 = dofs[rec["problem"], np.minimum(rec["t"] + 1, T - 1)]
