@@ -8,17 +8,20 @@ anything here touches the GPU) and exits with their code; started BY torch.distr
 of those ranks.  One rank per GPU, problems partitioned over the ranks, no data-path collective ("scaling": "weak").
 
 Workloads (config.workload):
-  fullbody   (default) BASELINE.json configs[3] -- full-body PR2-like robot (K=18), 100 timesteps, against a 4096-hull
-             convex soup, d = 0.09 -- batched as `problems_per_gpu` (64) independent multi-start trajectories per GPU;
-  fullbody42 a side line: the same with every hull at its full 42 vertices (the default's hulls average 16: the 42
-             support directions of a 120-point blob often pick the same point);
+  fullbody42 (default) BASELINE.json configs[3] as BASELINE.md's table words it -- full-body PR2-like robot (K=18), 100
+             timesteps, against a convex soup of 4096 children of 42 vertices each (what btShapeHull leaves of a dense
+             mesh, bullet_collision_checker.cpp:174-203), d = 0.09 -- batched as `problems_per_gpu` (64) independent
+             multi-start trajectories per GPU;
+  fullbody   the lighter soup rounds 1 and 2 were quoted on (hulls of the 42 support directions of a 120-point blob: the
+             directions often pick the same point, ~16 vertices per hull); measured briefly as a side line of the
+             default run (`side_workloads.fullbody16`) so that the rounds stay comparable;
   multistart BASELINE.json configs[4], one GPU's share: 1024 independent python_examples/benchmark.py-shaped problems
              (right arm K=7, T=11, discrete + cast) in the reference's kitchen_counter world (52 boxes).
 One STEP = one SQP linearization of every problem on the rank: the discrete collision cost (self collision included)
 and the cast collision cost, contacts + gradient rows, into one device slab -- FK, broadphase, GJK, EPA and the Jacobian
 epilogue all inside the timed region; the DOF vectors are already resident in HBM (tohc_stage_dofs).
 `value` = pair-evals of all ranks / max-over-ranks wall time of a block of K steps (barrier + synchronize on both
-sides); the block is repeated until >= 1 s has been timed and the MEDIAN block is reported.  `value` stops at the
+sides); the block is repeated until >= --min-seconds (5 s) have been timed and the MEDIAN block is reported.  `value` stops at the
 device slab; `value_host_delivered` is the same workload through stage + enqueue + fetch (slab in canonical order in
 pinned host memory, PCIe included) -- SURVEY 8(d)'s "result delivered in host memory".  It is never `value`.
 """
@@ -88,13 +91,61 @@ def workload_text(config, P, T, K):
                 "costs with gradient rows) in the reference's kitchen_counter world (52 boxes), d=0.09" % (P, K, T))
     return ("configs[3]%s: full-body PR2-like (K=%d) x %d timesteps vs 4096-hull convex soup, d=0.09, discrete+cast collision costs with "
             "gradient rows; %d independent multi-start problems per GPU"
-            % (" with full 42-vertex hulls (every blob dense enough that the 42 support directions pick distinct points)" if config == "fullbody42" else "", K, T, P))
+            % (" as BASELINE.md's table has it, 4096 convex children of 42 vertices each" if config == "fullbody42" else
+               " with the lighter hulls of rounds 1-2 (~16 vertices per child)", K, T, P))
+
+
+def measure_side(config, P, steps, device):
+    """A short measurement of another workload on the same GPU (rank 0, N = 1 only; never `value`): the timed step as in
+    main() for >= 1 s, and one problem's linearization latency."""
+    import torch
+    s, rb, static_T, d, cc, dofs = build_world(config, 0, 1, P)
+    eng = cc.eng
+    T = dofs.shape[1]
+    eng.stage_dofs(dofs, P, T)
+    for _ in range(3):
+        eng.enqueue_linearization(-1, 1, True); eng.sync()
+    blocks, total = [], 0.0
+    while total < 1.0 and len(blocks) < 50:
+        c0 = eng.counters()["cum_pair_evals"]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.enqueue_linearization(-1, 1, True); eng.sync()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        blocks.append((dt, eng.counters()["cum_pair_evals"] - c0))
+        total += dt
+    blocks.sort()
+    dt, pe = blocks[len(blocks) // 2]
+    lat_host, lat_dev = single_problem_latency(eng, dofs, T)
+    a = s.arrays
+    nv = float(np.where(a["kind"][a["child_shape"]] == 1, a["vcnt"][a["child_shape"]], 8).mean())
+    out = {"workload": workload_text(config, P, T, rb.K), "value": pe / dt, "ms_per_step": dt / steps * 1e3, "mean_hull_vertices_all_children": nv,
+           "ms_per_sqp_linearization_single_problem_host_delivered": lat_host, "ms_per_sqp_linearization_single_problem_device": lat_dev}
+    eng.close()
+    return out
+
+
+def single_problem_latency(eng, dofs, T, reps=20):
+    """ONE problem's linearization (discrete + cast, gradient rows), results in host memory: median wall time of
+    enqueue + fetch with the DOF vectors staged, and the device span of the same call (HIP events)."""
+    eng.stage_dofs(dofs[:1], 1, T)
+    lat, dev = [], []
+    for i in range(reps + 3):
+        tl = time.perf_counter()
+        eng.enqueue_linearization(-1, 1, True)
+        eng.fetch(copy=False)
+        if i >= 3:
+            lat.append((time.perf_counter() - tl) * 1e3)
+            dev.append(eng.counters()["ms_last_call"])
+    return float(np.median(lat)), float(np.median(dev))
 
 
 # ----------------------------------------------------------------------------------------------------------------
 # CPU baseline (rank 0, N = 1 only)
 # ----------------------------------------------------------------------------------------------------------------
-def cpu_baseline(s, rb, static_T, d, allowed, trajs, budget_s=12.0, only=None):
+def cpu_baseline(s, rb, static_T, d, allowed, trajs, budget_s=12.0, only=None, single_problem=False):
     """The CPU path on ONE host core, on a bounded sample of the same workload: timesteps of the rank's problems, each
     problem taken with a stride of 7, problem after problem until ~budget_s of work.  kind=reference: the reference's own
     vendored Bullet (oracle/_ref) doing LinksVsAll + CastVsAll on poses from the oracle's FK (FK / Jacobian time NOT
@@ -117,6 +168,11 @@ def cpu_baseline(s, rb, static_T, d, allowed, trajs, budget_s=12.0, only=None):
             break
     dt = time.perf_counter() - t0
     out["port"] = dict(value=(wo.counter(0) - pe0) / max(dt, 1e-9), seconds=dt, timesteps=used)
+    if single_problem and only != "reference" and not B.ref_available():   # (with the reference at hand its figure is the one reported)
+        t0 = time.perf_counter()
+        wo.linearize(rb, static_T, trajs[0])
+        wo.linearize(rb, static_T, trajs[0], cast=True)
+        out["port"]["ms_per_linearization_single_problem"] = (time.perf_counter() - t0) * 1e3
     if only == "port":
         wo.close()
         return out
@@ -148,6 +204,19 @@ def cpu_baseline(s, rb, static_T, d, allowed, trajs, budget_s=12.0, only=None):
             if tsum > budget_s:
                 break
         out["reference"] = dict(value=(lib.ref_gjk_checks() - g0) / tsum, seconds=tsum, timesteps=used)
+        if single_problem:
+            # metric (2), "ms per SQP linearization", on the CPU: ONE whole problem (problem 0: T LinksVsAll + T-1 CastVsAll
+            # calls, what convexifyCosts triggers) on one core; FK / Jacobian time is not charged to it
+            tl = 0.0
+            fks = [poses(trajs[0, t]) for t in range(T)]
+            for t in range(T):
+                P0, fk0 = fks[t]
+                t0 = time.perf_counter()
+                wr.links_vs_all(P0, objs)
+                if t + 1 < T:
+                    wr.cast_vs_all(P0, objs, fk0[links], fks[t + 1][1][links])
+                tl += time.perf_counter() - t0
+            out["reference"]["ms_per_linearization_single_problem"] = tl * 1e3
         wr.close()
     wo.close()
     return out
@@ -259,15 +328,15 @@ def dry_run(args, world, rank):
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
-        cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]), sys.argv[6] if len(sys.argv) > 6 else "fullbody")
+        cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]), sys.argv[6] if len(sys.argv) > 6 else "fullbody42")
         return 0
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=["fullbody", "fullbody42", "multistart"], default="fullbody")
+    ap.add_argument("--config", choices=["fullbody42", "fullbody", "multistart"], default="fullbody42")
     ap.add_argument("--problems-per-gpu", type=int, default=None, help="default: 64 (fullbody), 1024 (multistart)")
-    ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K-step block until this much has been timed; the median block is reported")
+    ap.add_argument("--min-seconds", type=float, default=5.0, help="repeat the K-step block until this much has been timed; the median block is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hot-path-only", action="store_true",
                     help="skip the side measurements (host-delivered rate, single-problem latency, ContinuousCheckTrajectory) so that every "
@@ -413,15 +482,7 @@ def main():
             pe += eng.counters()["pair_evals"]
         api = pe / (time.perf_counter() - ta)
         # latency of ONE problem's linearization, results in host memory (north-star: < 1 ms)
-        eng.stage_dofs(dofs[:1], 1, T)
-        lat = []
-        for _ in range(10):
-            tl = time.perf_counter()
-            linearize()
-            eng.fetch(copy=False)
-            lat.append((time.perf_counter() - tl) * 1e3)
-        lat_ms = float(np.median(lat))
-        lat_dev_ms = eng.counters()["ms_last_call"]
+        lat_ms, lat_dev_ms = single_problem_latency(eng, dofs, T)
         # ContinuousCheckTrajectory (the acceptance check of the reference's tests) of one problem, hits in host memory
         sw = []
         for _ in range(5):
@@ -530,16 +591,30 @@ def main():
                                   "of the metric is checked against the build's own fp64 FK model, finite differences and closed forms",
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 at N = 1 only
-            cb = cpu_baseline(s, rb, static_T, d, cc.allowed, dofs)
+            cb = cpu_baseline(s, rb, static_T, d, cc.allowed, dofs, single_problem=True)
             kind = "reference" if "reference" in cb else "port"
-            out["cpu_baseline"] = {"value": cb[kind]["value"], "unit": "pair-evals/s", "cores": 1, "kind": kind,
+            out["cpu_baseline"] = {"value": cb[kind]["value"],
+                                   "unit": "pair-evals/s (Bullet gNumGjkChecks)" if kind == "reference" else "pair-evals/s",
+                                   "unit_note": ("counted as Bullet's own gNumGjkChecks: GJK pair-detector calls of the reference's contactTest, its DBVT + compound "
+                                                 "culls in front -- close to, not the same as, the engine's box-cull survivors (`value`); FK / Jacobian time is not "
+                                                 "charged to the CPU" if kind == "reference" else
+                                                 "the C restatement's box-cull survivors (the engine's own unit); full linearization incl. FK and gradient rows"),
+                                   "cores": 1, "kind": kind,
                                    "sample": "%d (problem, timestep) units of this rank's workload (%.1f s of CPU work): discrete LinksVsAll + CastVsAll per unit on one core"
                                              % (cb[kind]["timesteps"], cb[kind]["seconds"]),
+                                   "ms_per_linearization_single_problem": cb[kind].get("ms_per_linearization_single_problem"),
+                                   "ms_per_linearization_single_problem_what": "problem 0 of the workload, all %d LinksVsAll + %d CastVsAll calls of one SQP linearization on one "
+                                                                               "core (beside ms_per_sqp_linearization_single_problem_host_delivered)" % (T, T - 1),
                                    "port_value": cb["port"]["value"]}
             try:   # the same on every host core of the job (north-star: "timed on the box's host cores, with the core count stated")
                 out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(cc.allowed, P, args.config)
             except Exception as ex:   # a reported extra: never fails the bench
                 out["cpu_baseline"]["all_cores"] = {"error": str(ex)[:200]}
+        if world == 1 and not args.hot_path_only and args.config == "fullbody42":
+            try:    # rounds 1-2 were quoted on the lighter soup: measured beside the headline so that the rounds stay comparable
+                out["side_workloads"] = {"fullbody16": measure_side("fullbody", P, args.steps, rank_device(rank))}
+            except Exception as ex:   # a reported extra: never fails the bench
+                out["side_workloads"] = {"error": str(ex)[:200]}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
