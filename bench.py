@@ -302,6 +302,78 @@ def profile_numbers(config):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# --shard timesteps: ONE large problem, its timesteps block-partitioned over the ranks (strong scaling)
+# ----------------------------------------------------------------------------------------------------------------
+def run_timestep_sharded(args, world, rank, dist):
+    """ONE configs[3] problem (the job's problem 0): rank r linearizes the timesteps multi_gpu.timestep_shard gives it --
+    its own discrete costs, its own cast pairs, one halo pose staged for the last pair -- with no data-path collective;
+    a step = tohc_enqueue_linearization_window + tohc_sync on every rank.  Afterwards (outside `value`) the one exchange
+    step: every shard's slab to every rank over RCCL, so that rank 0's SQP host holds the whole linearization."""
+    import torch
+    from trajopt_amd import multi_gpu
+    s, rb, static_T, d, cc, dofs = build_world(args.config, 0, 1, 1)     # the same problem 0 on every rank
+    eng = cc.eng
+    T = dofs.shape[1]
+    sh = multi_gpu.timestep_shard(T, world, rank, 1)
+    part = np.ascontiguousarray(dofs[:, sh["lo"]:sh["stage_hi"]])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        if sh["n_discrete"] > 0:
+            eng.enqueue_linearization_window(sh["n_discrete"], -1, 1, True)
+            eng.sync()
+
+    if sh["n_discrete"] > 0:
+        eng.stage_dofs(part, 1, part.shape[1])
+    for _ in range(args.warmup):
+        step()
+    blocks, total = [], 0.0
+    while True:
+        ca = eng.counters()["cum_pair_evals"]
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        dt_max, pairs_all = multi_gpu.reduce_measurement(dt, eng.counters()["cum_pair_evals"] - ca, dist, device="cuda")
+        blocks.append((dt_max, pairs_all))
+        total += dt_max
+        if total >= args.min_seconds or len(blocks) >= 200:
+            break
+    blocks.sort(key=lambda b: b[0])
+    dt_max, pairs_all = blocks[len(blocks) // 2]
+    gather_ms = None
+    n_all = eng.counters()["contacts"]
+    if dist is not None:
+        multi_gpu.all_gather_slabs_device(eng, dist)   # warm-up (communicator set-up)
+        barrier()
+        tg = time.perf_counter()
+        counts, _, _ = multi_gpu.all_gather_slabs_device(eng, dist)
+        barrier()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        n_all = int(counts.sum())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "signed-distance+Jacobian pair-evals/s (node)", "value": pairs_all / dt_max, "unit": "pair-evals/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ONE problem of " + workload_text(args.config, 1, T, rb.K), "timesteps": T, "K": rb.K,
+                       "parallelism": "timesteps of one problem block-partitioned over %d GPU(s) with a 1-pose halo, no data-path collective" % world},
+            "ms_per_sqp_linearization_single_problem_device_slab": dt_max / args.steps * 1e3,
+            "allgather_slabs_ms": gather_ms, "contacts_all_shards": n_all,
+            "timed": {"blocks": len(blocks), "seconds_total": total}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+    return 0
+
+
 def dry_run(args, world, rank):
     """No GPU: the rank set-up, the partition and the reductions of the real run over gloo, with a stub in place of the
     engine (CPU test of `--gpus N`)."""
@@ -344,6 +416,9 @@ def main():
     ap.add_argument("--two-calls", action="store_true",
                     help="enqueue the two passes of a linearization with tohc_enqueue_links_vs_all + tohc_enqueue_cast_vs_all (each with a "
                          "broadphase launch of its own) instead of tohc_enqueue_linearization")
+    ap.add_argument("--shard", choices=["problems", "timesteps"], default="problems",
+                    help="how N GPUs share the work: independent problems per GPU (weak scaling; the default and the driver's line), or the "
+                         "timesteps of ONE problem cut into N blocks with a 1-pose halo (strong scaling; fullbody configs)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: rank set-up, partition and reductions over gloo with a stub engine")
     args = ap.parse_args()
     if args.problems_per_gpu is None:
@@ -369,6 +444,11 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", rank_device(rank)))
     assert torch.cuda.is_available(), "bench.py needs a GPU: the engine has no CPU fallback"
     from trajopt_amd import multi_gpu
+    if args.shard == "timesteps":
+        if args.config == "multistart":
+            print("bench.py: --shard timesteps is for the one-large-problem configs (fullbody42 / fullbody)", file=sys.stderr)
+            return 2
+        return run_timestep_sharded(args, world, rank, dist)
 
     P = args.problems_per_gpu
     s, rb, static_T, d, cc, dofs = build_world(args.config, rank, world, P)

@@ -155,6 +155,16 @@ int tohc_enqueue_cast_vs_all(tohc_engine *e, int gap, int want_jacobians, int ap
  * enqueue -- same records, gradient rows and counters -- with one broadphase launch for both passes where the engine's
  * set-up allows (the cast pass's query boxes hold the discrete pass's). */
 int tohc_enqueue_linearization(tohc_engine *e, int filter_mask, int gap, int want_jacobians);
+/* The same for ONE SHARD of a trajectory cut by timestep over several GPUs ("timesteps block-partitioned with
+ * a 1-pose halo").  The reference makes one collision cost per timestep and one per (t, t + gap), each independent of the
+ * others (problem_description.cpp:516-529; CastCollisionEvaluator reads exactly the variables of its two timesteps,
+ * collision_terms.cpp:156-161), so a shard that owns timesteps [lo, hi) stages the poses [lo, min(hi + gap, T)) and asks
+ * for the discrete pass over its own n_discrete = hi - lo of them and the cast pass over every staged pair: the last `gap`
+ * poses are the halo, the second pose of its last cast pairs and some other shard's discrete timesteps.  1 <= n_discrete
+ * <= the staged timestep count (equal: the shard that holds the trajectory's end, same as tohc_enqueue_linearization).
+ * record.t counts from the shard's first pose; the union of the shards' slabs, t shifted by lo, is the single-GPU slab
+ * (trajopt_amd/multi_gpu.py: timestep_shard, merge_timestep_shards). */
+int tohc_enqueue_linearization_window(tohc_engine *e, int filter_mask, int gap, int want_jacobians, int n_discrete);
 int tohc_sync(tohc_engine *e);
 int tohc_fetch(tohc_engine *e, const tohc_record **records, const double **grads, int *n_records);
 

@@ -1121,6 +1121,7 @@ static int narrowPrepare(tohc_engine *e, const DynMap &dm, const int *d_qchildre
   cp.seg_cap = (unsigned int)(e->max_pairs / TOHC_NSHARD); cp.max_records = (unsigned int)e->max_records;
   cp.dbg_max_iter = getenv("TOHC_DBG_MAXITER") ? atoi(getenv("TOHC_DBG_MAXITER")) : 1000;
   cp.epa_small_v = e->epa_small_v; cp.epa_small_f = e->epa_small_f;
+  if (cp.t_disc <= 0) cp.t_disc = cp.T;   // (no window: the discrete pass covers every staged timestep)
   const size_t qcap = (size_t)cp.seg_cap * TOHC_NSHARD;
   HIPCHK(ln.pairs.reserve(qcap)); HIPCHK(ln.epaq.reserve(qcap)); HIPCHK(ln.hits.reserve(qcap));
   HIPCHK(ln.penq.reserve((size_t)(cp.seg_cap / TOHC_PEN_DIV) * TOHC_NSHARD));
@@ -1349,10 +1350,12 @@ int tohc_stage_dofs(tohc_engine *e, const double *dofs, int B, int T) {
   return TOHC_OK;
 }
 
-static int enqueueRobot(tohc_engine *e, int gap, int cast, int filter_mask, int want_jac, int append) {
+// t_disc: the discrete pass covers the first t_disc timesteps of every staged trajectory (0 = all of them)
+static int enqueueRobot(tohc_engine *e, int gap, int cast, int filter_mask, int want_jac, int append, int t_disc = 0) {
   if (!e) return TOHC_E_INVALID;
   if (!e->staged) return fail(e, TOHC_E_STATE, "stage the DOF vectors first (tohc_stage_dofs)");
   if (cast && gap < 1) return fail(e, TOHC_E_INVALID, "cast: gap must be >= 1");
+  if (t_disc < 0 || t_disc > e->staged_T) return fail(e, TOHC_E_INVALID, "discrete window: 0 <= n_discrete <= staged timesteps");
   HIPCHK(hipSetDevice(e->device));
   int slot;
   int rc = nextSlot(e, &slot);
@@ -1381,7 +1384,8 @@ static int enqueueRobot(tohc_engine *e, int gap, int cast, int filter_mask, int 
   CallParams cp;
   memset(&cp, 0, sizeof cp);
   cp.T = T; cp.gap = cast ? gap : 0; cp.cast = cast; cp.filter_mask = filter_mask; cp.want_jac = want_jac; cp.d = e->d; cp.breaking = e->breaking;
-  const int units = cast ? B * std::max(T - gap, 0) : B * T;
+  cp.t_disc = t_disc > 0 ? t_disc : T;
+  const int units = cast ? B * std::max(T - gap, 0) : B * cp.t_disc;
   e->last_sets = (int64_t)n_sets;
   if (!append || (e->slab_state == 0 && e->pending.empty())) e->slab_B = B, e->slab_disc_passes = e->slab_cast_passes = 0, e->slab_gap = 0;
   if (cast) { if (e->slab_cast_passes++ > 0 && e->slab_gap != gap) e->slab_gap = -1; else e->slab_gap = gap; }
@@ -1410,14 +1414,20 @@ static int enqueueRobot(tohc_engine *e, int gap, int cast, int filter_mask, int 
 // gap) of one SQP linearization -- what tohc_enqueue_links_vs_all(append = 0) followed by tohc_enqueue_cast_vs_all(append
 // = 1) enqueue, same records, same counters -- with ONE broadphase launch for both passes when the engine's set-up allows
 // it (k_broadphase_both), else as those two calls.
-static int enqueueBoth(tohc_engine *e, int filter_mask, int gap, int want_jac) {
+// t_disc: 0 (all), or the number of timesteps the discrete pass covers: the first t_disc of every staged trajectory; the
+// rest are only there as second poses of this shard's last cast pairs (tohc_enqueue_linearization_window)
+static int enqueueBoth(tohc_engine *e, int filter_mask, int gap, int want_jac, int t_disc = 0) {
   if (!e) return TOHC_E_INVALID;
   if (!e->staged) return fail(e, TOHC_E_STATE, "stage the DOF vectors first (tohc_stage_dofs)");
   if (gap < 1) return fail(e, TOHC_E_INVALID, "cast: gap must be >= 1");
   const int B = e->staged_B, T = e->staged_T;
-  const bool fuse = e->fuse_broadphase && e->n_lanes >= 2 && e->chunks == 1 && e->defer_exact && e->pretest && T > gap && !getenv("TOHC_BP_DBG");
+  if (t_disc == 0) t_disc = T;
+  if (t_disc < 1 || t_disc > T) return fail(e, TOHC_E_INVALID, "linearization window: 1 <= n_discrete <= staged timesteps");
+  // one launch covers the discrete pass's units: all T timesteps, or the first T - gap (then exactly the cast pass's units)
+  const bool fuse = e->fuse_broadphase && e->n_lanes >= 2 && e->chunks == 1 && e->defer_exact && e->pretest && T > gap && !getenv("TOHC_BP_DBG") &&
+                    (t_disc == T || t_disc == T - gap);
   if (!fuse) {
-    const int rc = enqueueRobot(e, 0, 0, filter_mask, want_jac, 0);
+    const int rc = enqueueRobot(e, 0, 0, filter_mask, want_jac, 0, t_disc);
     return rc != TOHC_OK ? rc : enqueueRobot(e, gap, 1, -1, want_jac, 1);
   }
   HIPCHK(hipSetDevice(e->device));
@@ -1444,7 +1454,8 @@ static int enqueueBoth(tohc_engine *e, int filter_mask, int gap, int want_jac) {
   CallParams cpD, cpC;
   memset(&cpD, 0, sizeof cpD);
   cpD.T = T; cpD.gap = 0; cpD.cast = 0; cpD.filter_mask = filter_mask; cpD.want_jac = want_jac; cpD.d = e->d; cpD.breaking = e->breaking;
-  cpD.unit_base = 0; cpD.n_cast_sets = B * T;
+  cpD.t_disc = t_disc;
+  cpD.unit_base = 0; cpD.n_cast_sets = B * t_disc;
   cpC = cpD;
   cpC.gap = gap; cpC.cast = 1; cpC.filter_mask = -1; cpC.n_cast_sets = B * (T - gap);
   e->last_sets = (int64_t)n_sets;
@@ -1489,6 +1500,10 @@ static int enqueueBoth(tohc_engine *e, int filter_mask, int gap, int want_jac) {
 }
 int tohc_enqueue_linearization(tohc_engine *e, int filter_mask, int gap, int want_jacobians) {
   return enqueueBoth(e, filter_mask, gap, want_jacobians);
+}
+int tohc_enqueue_linearization_window(tohc_engine *e, int filter_mask, int gap, int want_jacobians, int n_discrete) {
+  if (e && n_discrete <= 0) return fail(e, TOHC_E_INVALID, "linearization window: 1 <= n_discrete <= staged timesteps");
+  return enqueueBoth(e, filter_mask, gap, want_jacobians, n_discrete);
 }
 
 int tohc_enqueue_links_vs_all(tohc_engine *e, int filter_mask, int want_jacobians, int append) {

@@ -140,6 +140,8 @@ struct CallParams {
   int ordered_pairs;         // AllVsAll: a query child meets only the children of objects with a higher number
   unsigned int epa_small_v, epa_small_f;   // k_tail_epa's first-attempt pools (<= TOHC_EPA_SMALL_V / _F; smaller only in tests)
   int gjk_split;             // k_gjk (a lane per pair) hands a run to k_gjk_cont after this many passes of the loop; 0 = never
+  int t_disc;                // discrete pass: it covers the first t_disc timesteps of each problem's T staged ones (T, or T - gap when the
+                             // last `gap` poses are another shard's: tohc_enqueue_linearization_window)
 };
 
 __host__ __device__ __forceinline__ Xf ldXf(const float *p) {
@@ -161,7 +163,7 @@ __device__ __forceinline__ Aabb ldAabb(const float *p) {
   return b;
 }
 __device__ __forceinline__ void castSets(const CallParams &cp, int cs, int &set0, int &set1) {
-  int per = cp.cast ? (cp.T - cp.gap) : cp.T;
+  int per = cp.cast ? (cp.T - cp.gap) : cp.t_disc;
   set0 = (cs / per) * cp.T + cs % per;
   set1 = set0 + (cp.cast ? cp.gap : 0);
 }
@@ -719,12 +721,12 @@ __global__ void __launch_bounds__(TOHC_BP_THREADS, TOHC_BP_WAVES) k_broadphase_b
   __shared__ int s_q[TOHC_BP_QCAP];
   const int lane = threadIdx.x;
   const int qi = blockIdx.x % cd.nQ;
-  const int u = blockIdx.x / cd.nQ;          // the discrete pass's unit = pose set (problem * T + t)
+  const int u = blockIdx.x / cd.nQ;          // the discrete pass's unit: timestep t < t_disc of a problem (t_disc = T, or T - gap: then every unit has a cast unit)
   const int T = cpd.T, gap = cpc.gap;
-  const int prob = u / T, t = u % T;
+  const int prob = u / cpd.t_disc, t = u % cpd.t_disc;
   const bool hasCast = t < T - gap;          // wave-uniform
   const int csC = prob * (T - gap) + t;      // the cast pass's unit
-  const int set0 = u, set1 = u + gap;
+  const int set0 = prob * T + t, set1 = set0 + gap;
   const TOHC_CONST_AS int *qinfo = uniformPtr(cd.qchildren + 4 * qi);   // (child, object, moving slot or -1, 0)
   const int q = qinfo[0], Q = qinfo[1], qs = qinfo[2];
   const int shard = blockIdx.x % TOHC_NSHARD;

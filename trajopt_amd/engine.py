@@ -70,6 +70,7 @@ SYMBOLS = {
     "tohc_enqueue_links_vs_all": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "tohc_enqueue_cast_vs_all": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "tohc_enqueue_linearization": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "tohc_enqueue_linearization_window": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tohc_sync": (C.c_int, [C.c_void_p]),
     "tohc_fetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(_f64p), C.POINTER(C.c_int)]),
     "tohc_fetch_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -237,6 +238,12 @@ class Engine:
         """A new slab = enqueue_links_vs_all(filter_mask, append=False) + enqueue_cast_vs_all(gap, append=True), with one
         broadphase launch for both passes where the engine can (tohc_enqueue_linearization)."""
         self._chk(self.lib.tohc_enqueue_linearization(self.h, int(filter_mask), int(gap), int(want_jacobians)))
+
+    def enqueue_linearization_window(self, n_discrete, filter_mask=-1, gap=1, want_jacobians=True):
+        """One timestep shard's linearization: the discrete pass over the first n_discrete staged timesteps (the staged count
+        T, or T - gap when the last `gap` poses are the halo), the cast pass over every staged pair
+        (tohc_enqueue_linearization_window; multi_gpu.timestep_shard says what to stage)."""
+        self._chk(self.lib.tohc_enqueue_linearization_window(self.h, int(filter_mask), int(gap), int(want_jacobians), int(n_discrete)))
 
     def sync(self):
         self._chk(self.lib.tohc_sync(self.h))

@@ -1,5 +1,7 @@
-"""Multi-GPU layout of the linearization path: one process per GPU, independent problems (multi-start trajectories,
-BASELINE.json configs[4]) partitioned over the ranks.  Computing the linearizations needs NO collective -- a rank's
+"""Multi-GPU layout of the linearization path: one process per GPU.  Two ways to cut the work, neither with a data-path
+collective: independent problems (multi-start trajectories, BASELINE.json configs[4]) partitioned over the ranks, or the
+TIMESTEPS of one large problem (configs[3]) block-partitioned with a halo of `gap` poses (timestep_shard /
+merge_timestep_shards below).  Computing the linearizations needs NO collective -- a rank's
 contacts and gradient rows belong to its own problems; the exchanges of the measurement are the barrier and two scalar
 reductions (max wall time, summed pair evaluations).  The one real exchange step of the north-star is optional and
 comes AFTER the path: every rank's result slab to every rank (so that a single SQP host can read all of them from one
@@ -18,6 +20,38 @@ def partition(n_problems, world_size, rank):
     base, extra = divmod(n_problems, world_size)
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
+
+
+def timestep_shard(T, world_size, rank, gap=1):
+    """Rank `rank`'s share of ONE trajectory of T timesteps.  The reference hatches one collision cost per timestep and one
+    per (t, t + gap), each reading only its own timesteps' variables (problem_description.cpp:516-529,
+    collision_terms.cpp:156-161), so the costs shard by timestep with no exchange: the rank owns the discrete costs of
+    [lo, hi) and the cast costs of the pairs starting in [lo, min(hi, T - gap)), and needs the poses [lo, stage_hi) for them,
+    stage_hi = min(hi + gap, T) -- its last `gap` poses are the halo (another rank's timesteps).
+    -> dict(lo, hi, stage_hi, n_discrete): stage dofs[:, lo:stage_hi], then
+    Engine.enqueue_linearization_window(n_discrete, gap=gap) (tohc_enqueue_linearization_window)."""
+    if gap < 1:
+        raise ValueError("gap must be >= 1")
+    lo, hi = partition(T, world_size, rank)
+    return dict(lo=lo, hi=hi, stage_hi=min(hi + gap, T), n_discrete=hi - lo)
+
+
+def shift_timesteps(records, lo):
+    """A shard's records count timesteps from its first staged pose; shift them to the trajectory's numbering."""
+    out = records.copy()
+    out["t"] += lo
+    return out
+
+
+def merge_timestep_shards(recs, grads):
+    """The shards' slabs (records already shifted, shift_timesteps; in rank order) as ONE slab in the engine's canonical
+    order -- (problem, t, discrete before cast, then the engine's own order inside a shard, which a stable sort keeps) --
+    i.e. what a single GPU's tohc_fetch returns for the whole trajectory.  grads: list of [n, 2, K] arrays or Nones."""
+    rec = np.concatenate(recs) if recs else np.zeros(0)
+    g = None if any(x is None for x in grads) else np.concatenate(grads)
+    order = np.lexsort((rec["cctype"] != 0, rec["t"], rec["problem"]))   # stable: ties keep the shard's order
+    # (a (problem, t, kind) group lives in exactly one shard, so the order inside it is that shard's canonical order)
+    return rec[order], (None if g is None else g[order])
 
 
 def reduce_measurement(seconds, units, dist=None, device="cpu"):
