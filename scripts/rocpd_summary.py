@@ -2,6 +2,8 @@
    python scripts/rocpd_summary.py stats  <results.db> <out.csv>      per-kernel calls / total / average / min / max (ns)
    python scripts/rocpd_summary.py pmc    <results.db> <out.csv>      per-kernel mean of every collected counter per launch
    python scripts/rocpd_summary.py hbm    <fetch.db> <write.db> <out.csv>   HBM bytes per launch from the FETCH_SIZE and the WRITE_SIZE pass
+   python scripts/rocpd_summary.py timeline <results.db> <out.csv> [first kernel name part]   the LAST repetition of a launch sequence
+                                          (from the last launch whose name holds that part, default k_fk): start / end offsets in us
 """
 import csv
 import sqlite3
@@ -62,5 +64,21 @@ def hbm(db_fetch, db_write, out):
             w.writerow([short(k), d["launches"], "%.1f" % fe, "%.1f" % wr, "%.0f" % ((2 * fe + wr) * 1024)])
 
 
+def timeline(db, out, first="k_fk"):
+    c = sqlite3.connect(db)
+    rows = c.execute("select name, start, end from kernels order by start").fetchall()
+    idx = [i for i, r in enumerate(rows) if first in r[0]]
+    if len(idx) >= 2:       # the last complete repetition
+        rows = rows[idx[-2]:idx[-1]]
+    t0 = rows[0][1]
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "start_us", "end_us", "duration_us", "gap_before_us"])
+        last_end = t0
+        for n, s_, e_ in rows:
+            w.writerow([short(n)[:70], "%.1f" % ((s_ - t0) / 1e3), "%.1f" % ((e_ - t0) / 1e3), "%.1f" % ((e_ - s_) / 1e3), "%.1f" % ((s_ - last_end) / 1e3)])
+            last_end = max(last_end, e_)
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc, "hbm": hbm}[sys.argv[1]](*sys.argv[2:])
+    {"stats": stats, "pmc": pmc, "hbm": hbm, "timeline": timeline}[sys.argv[1]](*sys.argv[2:])

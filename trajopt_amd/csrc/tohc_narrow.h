@@ -232,31 +232,77 @@ TOHC_DEV V3 hullMaxDot(const Cvx<G> &c, V3 d) {
 #if defined(__HIPCC__)
 typedef float Pk2 __attribute__((ext_vector_type(2)));
 #endif
+struct VBlock { F4 xa, xb, ya, yb, za, zb; };   // one block of the table in registers: x[8] y[8] z[8]
+TOHC_DEV VBlock ldBlock(const float *vb, int i0) {
+  const F4 *b = reinterpret_cast<const F4 *>(vb + 3 * i0);
+  VBlock o;
+  o.xa = b[0]; o.xb = b[1]; o.ya = b[2]; o.yb = b[3]; o.za = b[4]; o.zb = b[5];
+  return o;
+}
+// the scan's step over one block: (best, bv) = the running maximum of dot(d, vertex) and its vertex
+TOHC_DEV void scanBlock(const VBlock &B, V3 d, float &best, V3 &bv) {
+  const float xs[8] = {B.xa.x, B.xa.y, B.xa.z, B.xa.w, B.xb.x, B.xb.y, B.xb.z, B.xb.w};
+  const float ys[8] = {B.ya.x, B.ya.y, B.ya.z, B.ya.w, B.yb.x, B.yb.y, B.yb.z, B.yb.w};
+  const float zs[8] = {B.za.x, B.za.y, B.za.z, B.za.w, B.zb.x, B.zb.y, B.zb.z, B.zb.w};
+#pragma unroll
+  for (int k = 0; k < 8; k += 2) {
+#if defined(__HIPCC__)
+    const Pk2 X = {xs[k], xs[k + 1]}, Y = {ys[k], ys[k + 1]}, Z = {zs[k], zs[k + 1]};
+    const Pk2 dt = (X * d.x + Y * d.y) + Z * d.z;
+    const float dt0 = dt.x, dt1 = dt.y;
+#else
+    const float dt0 = xs[k] * d.x + ys[k] * d.y + zs[k] * d.z, dt1 = xs[k + 1] * d.x + ys[k + 1] * d.y + zs[k + 1] * d.z;
+#endif
+    if (dt0 > best) { best = dt0; bv = mk(xs[k], ys[k], zs[k]); }
+    if (dt1 > best) { best = dt1; bv = mk(xs[k + 1], ys[k + 1], zs[k + 1]); }
+  }
+}
+TOHC_DEV V3 scanResult(const Cvx<1> &c, float best, V3 bv) {
+  if (!(best > -INFINITY) && c.n > 0) bv = mk(c.vb[0], c.vb[8], c.vb[16]);  // all-NaN dots: index 0, like the scan
+  return bv;
+}
 template <>
 TOHC_DEV V3 hullMaxDot<1>(const Cvx<1> &c, V3 d) {
   float best = -INFINITY;
   V3 bv = mk(0, 0, 0);
   for (int i0 = 0; i0 < c.n; i0 += 8) {
-    const F4 *b = reinterpret_cast<const F4 *>(c.vb + 3 * i0);
-    const F4 xa = b[0], xb = b[1], ya = b[2], yb = b[3], za = b[4], zb = b[5];
-    const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-    const float ys[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
-    const float zs[8] = {za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w};
-#pragma unroll
-    for (int k = 0; k < 8; k += 2) {
-#if defined(__HIPCC__)
-      const Pk2 X = {xs[k], xs[k + 1]}, Y = {ys[k], ys[k + 1]}, Z = {zs[k], zs[k + 1]};
-      const Pk2 dt = (X * d.x + Y * d.y) + Z * d.z;
-      const float dt0 = dt.x, dt1 = dt.y;
-#else
-      const float dt0 = xs[k] * d.x + ys[k] * d.y + zs[k] * d.z, dt1 = xs[k + 1] * d.x + ys[k + 1] * d.y + zs[k + 1] * d.z;
-#endif
-      if (dt0 > best) { best = dt0; bv = mk(xs[k], ys[k], zs[k]); }
-      if (dt1 > best) { best = dt1; bv = mk(xs[k + 1], ys[k + 1], zs[k + 1]); }
-    }
+    const VBlock b = ldBlock(c.vb, i0);
+    scanBlock(b, d, best, bv);
   }
-  if (!(best > -INFINITY) && c.n > 0) bv = mk(c.vb[0], c.vb[8], c.vb[16]);  // all-NaN dots: index 0, like the scan
-  return bv;
+  return scanResult(c, best, bv);
+}
+// The same scan for TWO directions in one pass over the table (the swept shape's support asks the same hull along d and
+// along d in the second pose's frame): each block is loaded once.  Per direction the arithmetic and the order are hullMaxDot's.
+TOHC_DEV void hullMaxDot2(const Cvx<1> &c, V3 d0, V3 d1, V3 &v0, V3 &v1) {
+  float best0 = -INFINITY, best1 = -INFINITY;
+  V3 bv0 = mk(0, 0, 0), bv1 = mk(0, 0, 0);
+  for (int i0 = 0; i0 < c.n; i0 += 8) {
+    const VBlock b = ldBlock(c.vb, i0);
+    scanBlock(b, d0, best0, bv0);
+    scanBlock(b, d1, best1, bv1);
+  }
+  v0 = scanResult(c, best0, bv0);
+  v1 = scanResult(c, best1, bv1);
+}
+// Two HULLS at once -- the two operands of a Minkowski support query are independent scans, each a chain of L2 round
+// trips (a block's six loads, then its compares): walking both tables in one loop keeps twice the loads in flight.  A
+// hull with fewer blocks than the other re-reads its last block (a copy never wins the strict '>').  two: the hull is
+// swept, its second direction is scanned in the same pass (hullMaxDot2).
+TOHC_DEV void hullMaxDotPair(const Cvx<1> &A, V3 a0, bool twoA, V3 a1, const Cvx<1> &B, V3 b0, bool twoB, V3 b1, V3 &vA0, V3 &vA1, V3 &vB0, V3 &vB1) {
+  float bestA0 = -INFINITY, bestA1 = -INFINITY, bestB0 = -INFINITY, bestB1 = -INFINITY;
+  V3 pA0 = mk(0, 0, 0), pA1 = mk(0, 0, 0), pB0 = mk(0, 0, 0), pB1 = mk(0, 0, 0);
+  const int nA = A.n > 0 ? ((A.n - 1) & ~7) : 0, nB = B.n > 0 ? ((B.n - 1) & ~7) : 0;   // first vertex of each hull's last block
+  const int nMax = nA > nB ? nA : nB;
+  for (int i0 = 0; i0 <= nMax; i0 += 8) {
+    const VBlock ba = ldBlock(A.vb, i0 < nA ? i0 : nA);
+    const VBlock bb = ldBlock(B.vb, i0 < nB ? i0 : nB);
+    scanBlock(ba, a0, bestA0, pA0);
+    if (twoA) scanBlock(ba, a1, bestA1, pA1);
+    scanBlock(bb, b0, bestB0, pB0);
+    if (twoB) scanBlock(bb, b1, bestB1, pB1);
+  }
+  vA0 = scanResult(A, bestA0, pA0); vA1 = scanResult(A, bestA1, pA1);
+  vB0 = scanResult(B, bestB0, pB0); vB1 = scanResult(B, bestB1, pB1);
 }
 // vertex i of a hull, the same value in every lane of the group
 template <int G>
@@ -298,12 +344,41 @@ TOHC_DEV V3 supPlainVirtual(const Cvx<G> &c, V3 d) {
   if (c.kind == KIND_CYLZ) return cylZSupport(c.dims, d);   // btCylinderShape's virtual support + margin 0
   return hullMaxDot<G>(c, d);
 }
+// the swept shape's support from its two poses' supports (sv1 still in the second pose's frame) [bcc:826-830]
+template <int G>
+TOHC_DEV V3 castPick(const Cvx<G> &c, V3 d, V3 sv0, V3 sv1l) {
+  const V3 sv1 = xfApply(c.t01, sv1l);
+  return (dot(d, sv0) > dot(d, sv1)) ? sv0 : sv1;
+}
 template <int G>
 TOHC_DEV V3 supNV(const Cvx<G> &c, V3 d) {
   if (!c.cast) return supPlainNV<G>(c, d);
+  if constexpr (G == 1) {
+    if (c.kind == KIND_HULL) {   // one pass over the table for both poses' directions
+      V3 sv0, sv1;
+      hullMaxDot2(c, d, mulVM(d, c.t01.b), sv0, sv1);
+      return castPick<G>(c, d, sv0, sv1);
+    }
+  }
   V3 sv0 = supPlainVirtual<G>(c, d);  // CastHullShape::localGetSupportingVertex [bcc:826-830]
-  V3 sv1 = xfApply(c.t01, supPlainVirtual<G>(c, mulVM(d, c.t01.b)));
-  return (dot(d, sv0) > dot(d, sv1)) ? sv0 : sv1;
+  return castPick<G>(c, d, sv0, supPlainVirtual<G>(c, mulVM(d, c.t01.b)));
+}
+// supNV of both operands of a Minkowski support query.  One lane per pair and two hulls: ONE loop over both tables
+// (hullMaxDotPair); everything else: the two queries one after the other.  Values are supNV's.
+template <int G>
+TOHC_DEV void supPairNV(const Cvx<G> &A, V3 dA, const Cvx<G> &B, V3 dB, V3 &pA, V3 &qB) {
+  if constexpr (G == 1) {
+    if (A.kind == KIND_HULL && B.kind == KIND_HULL) {
+      const bool twoA = A.cast != 0, twoB = B.cast != 0;
+      V3 a0, a1, b0, b1;
+      hullMaxDotPair(A, dA, twoA, twoA ? mulVM(dA, A.t01.b) : dA, B, dB, twoB, twoB ? mulVM(dB, B.t01.b) : dB, a0, a1, b0, b1);
+      pA = twoA ? castPick<G>(A, dA, a0, a1) : a0;
+      qB = twoB ? castPick<G>(B, dB, b0, b1) : b0;
+      return;
+    }
+  }
+  pA = supNV<G>(A, dA);
+  qB = supNV<G>(B, dB);
 }
 // getMarginNonVirtual() of a GJK operand: the swept shape's is 0 (CastHullShape::getMargin, bcc:870)
 template <int G>
@@ -671,8 +746,8 @@ struct GjkRun {
   TOHC_DEV bool step(const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &tB, float maxDist2, int maxIter) {
     V3 sepA = mulVM(-sep, tA.b);
     V3 sepB = mulVM(sep, tB.b);
-    V3 pInA = supNV<G>(A, sepA);
-    V3 qInB = supNV<G>(B, sepB);
+    V3 pInA, qInB;
+    supPairNV<G>(A, sepA, B, sepB, pInA, qInB);
     V3 pW = mulMV(tA.b, pInA) + oA;
     V3 qW = mulMV(tB.b, qInB) + oB;
     V3 w = pW - qW;
@@ -826,7 +901,21 @@ TOHC_DEV V3 minkSupport1(const Mink<G> &m, V3 d) {
   return xfApply(m.toshape0, s);
 }
 template <int G>
-TOHC_DEV V3 minkSupport(const Mink<G> &m, V3 d) { return minkSupport0<G>(m, d) - minkSupport1<G>(m, -d); }
+TOHC_DEV V3 minkSupport(const Mink<G> &m, V3 d) {
+  if constexpr (G == 1) {   // both operands' scans in one loop (supPairNV); the values are those of the two calls below
+    const V3 d1 = mulMV(m.toshape1, -d);
+    const V3 n0 = m.margins ? normalizedOrMinus1(d) : d, n1 = m.margins ? normalizedOrMinus1(d1) : d1;
+    V3 s0, s1;
+    supPairNV<G>(*m.s0, n0, *m.s1, n1, s0, s1);
+    if (m.margins) {
+      const float m0 = cvxMargin<G>(*m.s0), m1 = cvxMargin<G>(*m.s1);
+      if (m0 != 0.0f) s0 = s0 + n0 * m0;
+      if (m1 != 0.0f) s1 = s1 + n1 * m1;
+    }
+    return s0 - xfApply(m.toshape0, s1);
+  }
+  return minkSupport0<G>(m, d) - minkSupport1<G>(m, -d);
+}
 
 TOHC_DEV float det3(V3 a, V3 b, V3 c) {
   return (a.y * b.z * c.x + a.z * b.x * c.y - a.x * b.z * c.y - a.y * b.x * c.z + a.x * b.y * c.z - a.z * b.y * c.x);
