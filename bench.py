@@ -131,6 +131,7 @@ def single_problem_latency(eng, dofs, T, reps=20):
     """ONE problem's linearization (discrete + cast, gradient rows), results in host memory: median wall time of
     enqueue + fetch with the DOF vectors staged, and the device span of the same call (HIP events)."""
     eng.stage_dofs(dofs[:1], 1, T)
+    eng.set_kernel_timing(False)     # a caller after latency leaves the per-stage timing events out (tohc_set_kernel_timing): ~35 us
     lat, dev = [], []
     for i in range(reps + 3):
         tl = time.perf_counter()
@@ -139,6 +140,7 @@ def single_problem_latency(eng, dofs, T, reps=20):
         if i >= 3:
             lat.append((time.perf_counter() - tl) * 1e3)
             dev.append(eng.counters()["ms_last_call"])
+    eng.set_kernel_timing(True)
     return float(np.median(lat)), float(np.median(dev))
 
 
@@ -648,6 +650,8 @@ def main():
             "mean_hull_vertices": {"query_children": n_q, "all_children": n_x},
             "ms_per_sqp_linearization_single_problem_host_delivered": lat_ms,
             "ms_per_sqp_linearization_single_problem_device": lat_dev_ms,
+            "ms_per_sqp_linearization_single_problem_note": "one problem: tohc_enqueue_linearization + tohc_fetch, DOF vectors staged, per-stage kernel timing "
+                                                            "events off (tohc_set_kernel_timing 0; the timed step above keeps them on: kernel_ms_per_pass)",
             "allgather_slabs_ms": gather_ms, "allgather_slabs_bytes": gather_bytes,
             "ms_continuous_check_trajectory_single_problem": sweep_ms,
             "continuous_check_hits_single_problem": n_sw,

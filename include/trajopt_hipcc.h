@@ -266,6 +266,12 @@ int tohc_ray_cast_poses_noalloc(tohc_engine *e, const double *d_obj_T, const dou
 int tohc_forward_kinematics(tohc_engine *e, const double *dofs, int n_cfg, double *link_T);
 
 int tohc_get_counters(const tohc_engine *e, tohc_counters *out);
+/* The per-stage times in tohc_counters (cum_ms_fk / _broadphase / _gjk / _epa / _finish) come from HIP events recorded
+ * between the kernels of every enqueue; each is a marker packet the next kernel of the stream waits behind.  on = 0 leaves
+ * them out (those fields then stay as they are; ms_last_call, the span of the call, is still measured): a single
+ * problem's linearization answers ~35 us sooner, a 64-problem step ~2 %.  Default on; TOHC_TIMING=0 in the environment
+ * sets the default off.  No counterpart in the reference. */
+int tohc_set_kernel_timing(tohc_engine *e, int on);
 
 /* capacity knobs (defaults sized for SURVEY config 4 on one MI355X).  max_pairs bounds, per enqueue, the pairs handed to
  * the iterative solver AND the pre-test's intermediate list (pairs whose bounding-sphere test could not separate them,

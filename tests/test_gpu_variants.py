@@ -336,3 +336,31 @@ def test_enqueue_linearization_equals_the_two_enqueues(built):
             assert np.array_equal(r2, r3), env
         finally:
             e.close()
+
+
+def test_kernel_timing_off_same_slab_and_span(built):
+    """tohc_set_kernel_timing(0) only leaves the per-stage event records out: same slab, same work counters, the span of
+    the call is still measured and the per-stage sums stand still."""
+    from trajopt_amd import collision_checker as CC
+    s, rb, static_T, d = synth.config_fullbody_soup(npts=0, n_hulls=512, seed=3)
+    dofs = np.stack([synth.fullbody_trajectory(rb, np.random.default_rng(70 + g), 9) for g in range(2)])
+    cc = CC.HIPCollisionChecker(s, static_T, None)
+    cc.SetRobot(rb); cc.SetContactDistance(d)
+    eng = cc.eng
+    eng.stage_dofs(dofs, 2, 9)
+    eng.enqueue_linearization(-1, 1, True)
+    rec, g = eng.fetch()
+    c_on = eng.counters()
+    eng.set_kernel_timing(False)
+    eng.enqueue_linearization(-1, 1, True)
+    rec2, g2 = eng.fetch()
+    c_off = eng.counters()
+    assert len(rec) > 0 and rec.tobytes() == rec2.tobytes() and g.tobytes() == g2.tobytes()
+    assert all(c_on[k] == c_off[k] for k in ("pair_evals", "gjk_evals", "epa_evals", "contacts", "aabb_tests"))
+    assert c_off["ms_last_call"] > 0 and c_on["cum_ms_gjk"] > 0
+    assert all(c_off[k] == c_on[k] for k in ("cum_ms_broadphase", "cum_ms_gjk", "cum_ms_epa", "cum_ms_finish"))
+    eng.set_kernel_timing(True)
+    eng.enqueue_linearization(-1, 1, True)
+    eng.sync()
+    assert eng.counters()["cum_ms_gjk"] > c_on["cum_ms_gjk"]
+    eng.close()

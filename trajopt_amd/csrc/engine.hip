@@ -215,6 +215,7 @@ struct tohc_engine {
   int gjk_group = 1;  // lanes per pair in k_gjk: 1 (default), 16 or 64 (TOHC_GJK_GROUP)
   int pen_group = 1;   // lanes per pair in k_pen: 1, or 4 (hull vertices in registers; TOHC_PEN_GROUP=4: measured no faster, GJK2's LDS bookkeeping dominates)
   int epa_block = 64;  // threads per k_epa block (TOHC_EPA_BLOCK = 16 or 64)
+  bool timing = true;  // per-stage timing events between the kernels (recEv)
   int unit_broadphase = 1024;   // k_broadphase_unit from this many units on (one wavefront per unit: fewer units leave the chip empty and
                                 // a wavefront per (unit, query child) answers sooner); TOHC_UNIT_BP=n sets it, 0 = never
   unsigned int epa_small_v = TOHC_EPA_SMALL_V, epa_small_f = TOHC_EPA_SMALL_F;   // TOHC_EPA_SMALL=v,f shrinks k_tail_epa's first-attempt pools (tests of the repeat path)
@@ -228,6 +229,10 @@ static const int RING = 32;
 // k_tail_epa, k_tail_range) [6] -- on the tail stream, real only for the last pass of a tail, a zero-length pair for
 // the others; [7] k_finish [8] -- on the lane again
 static const int NEV = 9;
+// The per-stage timing events of an enqueue (NEV per slot: tohc_counters' cum_ms_*).  Each record is a marker packet between
+// two kernels of a stream; with kernel timing off (tohc_set_kernel_timing / TOHC_TIMING=0) only the first and the last of a
+// slot are recorded -- the span of the call, ms_last_call -- and the kernels of a stream follow each other directly.
+static hipError_t recEv(tohc_engine *e, hipEvent_t *ev, int i, hipStream_t s);
 
 static int fail(tohc_engine *e, int code, const char *fmt, ...) {
   char buf[512];
@@ -240,6 +245,10 @@ static int fail(tohc_engine *e, int code, const char *fmt, ...) {
 }
 
 static int launchTail(tohc_engine *e);
+static hipError_t recEv(tohc_engine *e, hipEvent_t *ev, int i, hipStream_t s) {
+  if (!e->timing && i != 0 && i != NEV - 1) return hipSuccess;
+  return hipEventRecord(ev[i], s);
+}
 // nothing may still be running on the lanes when tables they read are replaced
 static hipError_t quiesce(tohc_engine *e) {
   if (launchTail(e) != TOHC_OK) return hipErrorUnknown;   // (e->err says what failed)
@@ -350,6 +359,7 @@ int tohc_create(tohc_engine **out, int device) {
   if (const char *mt = getenv("TOHC_MERGE_TAIL")) e->max_open = atoi(mt) != 0 ? TOHC_MAX_HEADS : 1;
   if (const char *eb = getenv("TOHC_EPA_BLOCK")) e->epa_block = atoi(eb) == 16 ? 16 : 64;
   if (const char *ub = getenv("TOHC_UNIT_BP")) e->unit_broadphase = std::max(atoi(ub), 0);
+  if (const char *tm = getenv("TOHC_TIMING")) e->timing = atoi(tm) != 0;
   if (const char *es = getenv("TOHC_EPA_SMALL")) {
     unsigned int v = 0, f = 0;
     if (sscanf(es, "%u,%u", &v, &f) == 2 && v >= 1 && f >= 4) { e->epa_small_v = std::min(v, (unsigned int)TOHC_EPA_SMALL_V); e->epa_small_f = std::min(f, (unsigned int)TOHC_EPA_SMALL_F); }
@@ -913,7 +923,7 @@ static int syncEngineImpl(tohc_engine *e) {
     c.cum_aabb_tests += pd.aabb_tests; c.cum_pair_evals += np; c.cum_epa_evals += ne; c.cum_gjk_evals += ng;
     float ms[NEV - 1] = {0, 0, 0, 0, 0, 0, 0, 0};
     hipEvent_t *ev = &e->events[(size_t)pd.slot * NEV];
-    for (int i = 0; i < NEV - 1; ++i)
+    for (int i = 0; i < NEV - 1 && e->timing; ++i)
       if (i != 4 && i != 6) HIPCHK(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));   // 4 -> 5 and 6 -> 7 are waits between streams
     c.cum_ms_fk += ms[0]; c.cum_ms_children += ms[1]; c.cum_ms_broadphase += ms[2]; c.cum_ms_gjk += ms[3]; c.cum_ms_epa += ms[5];
     c.cum_ms_finish += ms[7];
@@ -930,13 +940,14 @@ static int syncEngineImpl(tohc_engine *e) {
     HIPCHK(hipMemset(e->d_dbg.p, 0, sizeof h));
     if (h[0]) {
       fprintf(stderr, "[epa prof] evals %llu  mean wall %.2f us  max wall %.2f us  mean cycles %.0f\n", h[0], h[1] / (double)h[0] / 100.0, h[3] / 100.0, h[2] / (double)h[0]);
-      const char *nm[8] = {"init", "support", "expand(x3)", "findbest", "enclose", "newface x4", "evaluate", "-"};
+      const char *nm[8] = {"init", "support", "expand(x3)", "findbest", "enclose", "newface x4", "evaluate", "makeHorizon"};
+      fprintf(stderr, "   expansions through the exact walk %llu, ended by a face reached twice %llu\n", h[4], h[5]);
       fprintf(stderr, "   support vertices added (histogram 0..63):");
       for (int k = 0; k < 64; ++k) fprintf(stderr, " %llu", h[32 + k]);
       fprintf(stderr, "\n   highest face slot used / 2 (histogram 0..63):");
       for (int k = 0; k < 64; ++k) fprintf(stderr, " %llu", h[96 + k]);
       fprintf(stderr, "\n");
-      for (int k = 0; k < 7; ++k) fprintf(stderr, "   %-12s calls/eval %.2f  cycles/eval %.0f  cycles/call %.0f\n", nm[k], h[16 + k] / (double)h[0], h[8 + k] / (double)h[0], h[16 + k] ? h[8 + k] / (double)h[16 + k] : 0.0);
+      for (int k = 0; k < 8; ++k) fprintf(stderr, "   %-12s calls/eval %.2f  cycles/eval %.0f  cycles/call %.0f\n", nm[k], h[16 + k] / (double)h[0], h[8 + k] / (double)h[0], h[16 + k] ? h[8 + k] / (double)h[16 + k] : 0.0);
     }
   }
 #endif
@@ -1013,11 +1024,11 @@ static int launchTail(tohc_engine *e) {
   // the tail's time is booked on the last pass; the others get a zero-length pair of events
   for (size_t i = 0; i + 1 < heads.size(); ++i) {
     hipEvent_t *ev = &e->events[(size_t)heads[i].slot * NEV];
-    HIPCHK(hipEventRecord(ev[5], ts));
-    HIPCHK(hipEventRecord(ev[6], ts));
+    HIPCHK(recEv(e, ev, 5, ts));
+    HIPCHK(recEv(e, ev, 6, ts));
   }
   hipEvent_t *evl = &e->events[(size_t)heads.back().slot * NEV];
-  HIPCHK(hipEventRecord(evl[5], ts));
+  HIPCHK(recEv(e, evl, 5, ts));
   if (work) {
     const unsigned int nh = (unsigned int)ta.n_heads;
     const unsigned int gridN = 256 * 8;
@@ -1048,14 +1059,14 @@ static int launchTail(tohc_engine *e) {
   if (e->slab_read_pending) HIPCHK(hipStreamWaitEvent(ts, e->ev_slab_read, 0));
   if (e->have_ranged) HIPCHK(hipStreamWaitEvent(ts, e->tail_ranged, 0));   // record ranges are reserved in enqueue order
   hipLaunchKernelGGL(k_tail_range, dim3(1), dim3(1), 0, ts, ta);   // also for passes without work: they reserve an empty range
-  HIPCHK(hipEventRecord(evl[6], ts));
+  HIPCHK(recEv(e, evl, 6, ts));
   HIPCHK(hipEventRecord(e->tail_ranged, ts));
   e->have_ranged = true;
   for (const auto &h : heads) {
     tohc_engine::Lane &ln = e->lane[h.lane];
     hipEvent_t *ev = &e->events[(size_t)h.slot * NEV];
     HIPCHK(hipStreamWaitEvent(ln.stream, e->tail_ranged, 0));
-    HIPCHK(hipEventRecord(ev[7], ln.stream));
+    HIPCHK(recEv(e, ev, 7, ln.stream));
     if (!h.empty) {
       // LDS: one pair of gradient rows per group -- only the lane-per-joint epilogue (fast_jac: K <= TOHC_FAST_JAC_MAXK, so at
       // most 64 KB for groups of 4) touches them; the lane-per-column fall-back (wide K, mimic joints) asks for none
@@ -1063,7 +1074,7 @@ static int launchTail(tohc_engine *e) {
       if (e->group == 64) hipLaunchKernelGGL((k_finish<64>), dim3(256 * 2), dim3(256), (size_t)(256 / 64) * 2 * Kr * sizeof(double), ln.stream, h.a);
       else hipLaunchKernelGGL((k_finish<TOHC_FINISH_G>), dim3(256 * TOHC_FINISH_BLOCKS_PER_CU), dim3(256), (size_t)(256 / TOHC_FINISH_G) * 2 * Kr * sizeof(double), ln.stream, h.a);
     }
-    HIPCHK(hipEventRecord(ev[8], ln.stream));
+    HIPCHK(recEv(e, ev, 8, ln.stream));
     HIPCHK(hipEventRecord(ln.done, ln.stream));
   }
   HIPCHK(hipGetLastError());
@@ -1134,7 +1145,7 @@ static int narrowPrepare(tohc_engine *e, const DynMap &dm, const int *d_qchildre
 #endif
   HIPCHK(e->d_records.reserve(e->max_records));
   HIPCHK(e->d_grads.reserve(e->max_records * 2 * (size_t)K));
-  HIPCHK(hipEventRecord(ev[2], s));
+  HIPCHK(recEv(e, ev, 2, s));
   L.slot = slot; L.laneIdx = laneIdx; L.nQ = nQ; L.wantJ = wantJ; L.noSlab = noSlab; L.append = append; L.robotMode = robotMode;
   L.s = s; L.ev = ev; L.h_qchildren = &h_qchildren;
   tohc_engine::OpenHead &oh = L.oh;
@@ -1206,7 +1217,7 @@ static int narrowFinish(tohc_engine *e, NarrowLaunch &L) {
       if (cp.cast) hipLaunchKernelGGL((k_exact<true>), dim3(TOHC_EXACT_GRID), dim3(64), 0, s, L.ca);
       else hipLaunchKernelGGL((k_exact<false>), dim3(TOHC_EXACT_GRID), dim3(64), 0, s, L.ca);
     }
-    HIPCHK(hipEventRecord(ev[3], s));
+    HIPCHK(recEv(e, ev, 3, s));
     const int gridN = 256 * 8;
     if (e->gjk_group == 1) {  // one lane per pair, one wavefront per block
       if (cp.cast) hipLaunchKernelGGL((k_gjk<1, true, 64>), dim3(TOHC_GJK_GRID), dim3(64), 0, s, a);
@@ -1224,9 +1235,9 @@ static int narrowFinish(tohc_engine *e, NarrowLaunch &L) {
     }
     HIPCHK(hipGetLastError());
   } else {
-    HIPCHK(hipEventRecord(ev[3], s));
+    HIPCHK(recEv(e, ev, 3, s));
   }
-  HIPCHK(hipEventRecord(ev[4], s));
+  HIPCHK(recEv(e, ev, 4, s));
   HIPCHK(hipEventRecord(ln.head_done, s));
   e->open.push_back(L.oh);
   tohc_engine::Pending pd;
@@ -1271,7 +1282,7 @@ static int launchSweep(tohc_engine *e, const DynMap &dm, const int *d_qchildren,
   cp.dbg_max_iter = 1000;
   cp.epa_small_v = e->epa_small_v; cp.epa_small_f = e->epa_small_f;
   HIPCHK(e->d_records.reserve(e->max_records));
-  HIPCHK(hipEventRecord(ev[2], s));
+  HIPCHK(recEv(e, ev, 2, s));
   if (nQ > 0 && cp.n_cast_sets > 0) {
     const size_t blocks = (size_t)cp.n_cast_sets * nQ;
     if (blocks > 0x7fffffffull) return fail(e, TOHC_E_CAPACITY, "sweep grid too large (%zu blocks)", blocks);
@@ -1298,7 +1309,7 @@ static int launchSweep(tohc_engine *e, const DynMap &dm, const int *d_qchildren,
     hipLaunchKernelGGL(k_sweep, dim3((unsigned)blocks), dim3(64), 0, s, sa);
     HIPCHK(hipGetLastError());
   }
-  for (int i = 3; i < NEV; ++i) HIPCHK(hipEventRecord(ev[i], s));   // the whole sweep is booked under "broadphase"
+  for (int i = 3; i < NEV; ++i) HIPCHK(recEv(e, ev, i, s));   // the whole sweep is booked under "broadphase"
   HIPCHK(hipEventRecord(ln.done, s));
   tohc_engine::Pending pd;
   pd.slot = slot;
@@ -1370,16 +1381,16 @@ static int enqueueRobot(tohc_engine *e, int gap, int cast, int filter_mask, int 
     if (rc != TOHC_OK) return rc;
     hipStream_t s = e->stream;
     for (auto &ln : e->lane) HIPCHK(hipStreamWaitEvent(s, ln.done, 0));   // pending enqueues still read the tables
-    HIPCHK(hipEventRecord(ev[0], s));
+    HIPCHK(recEv(e, ev, 0, s));
     hipLaunchKernelGGL(k_fk, dim3((unsigned)n_sets), dim3(64), (size_t)e->n_links * 7 * sizeof(double), s, devRobot(e), devScene(e), dm, e->d_dofs.p,
                        (int)n_sets, e->d, e->d_linkQT.p, e->d_objQT.p, e->d_dynXf.p, e->d_dynAabb.p, e->d_linkZ.p, e->d_dynSph.p);
-    HIPCHK(hipEventRecord(ev[1], s));
+    HIPCHK(recEv(e, ev, 1, s));
     HIPCHK(hipEventRecord(e->ev_fk, s));
     e->fk_done = true;
   } else {
     hipStream_t ls = e->lane[slot % e->n_lanes].stream;
-    HIPCHK(hipEventRecord(ev[0], ls));
-    HIPCHK(hipEventRecord(ev[1], ls));
+    HIPCHK(recEv(e, ev, 0, ls));
+    HIPCHK(recEv(e, ev, 1, ls));
   }
   CallParams cp;
   memset(&cp, 0, sizeof cp);
@@ -1399,8 +1410,8 @@ static int enqueueRobot(tohc_engine *e, int gap, int cast, int filter_mask, int 
       if (rc != TOHC_OK) return rc;
       hipStream_t ls = e->lane[slot % e->n_lanes].stream;
       hipEvent_t *evc = &e->events[(size_t)slot * NEV];
-      HIPCHK(hipEventRecord(evc[0], ls));
-      HIPCHK(hipEventRecord(evc[1], ls));
+      HIPCHK(recEv(e, evc, 0, ls));
+      HIPCHK(recEv(e, evc, 1, ls));
     }
     cp.unit_base = (int)((int64_t)units * c / C);
     cp.n_cast_sets = (int)((int64_t)units * (c + 1) / C) - cp.unit_base;
@@ -1444,10 +1455,10 @@ static int enqueueBoth(tohc_engine *e, int filter_mask, int gap, int want_jac, i
     hipEvent_t *ev = &e->events[(size_t)slotD * NEV];
     hipStream_t s = e->stream;
     for (auto &ln : e->lane) HIPCHK(hipStreamWaitEvent(s, ln.done, 0));   // pending enqueues still read the tables
-    HIPCHK(hipEventRecord(ev[0], s));
+    HIPCHK(recEv(e, ev, 0, s));
     hipLaunchKernelGGL(k_fk, dim3((unsigned)n_sets), dim3(64), (size_t)e->n_links * 7 * sizeof(double), s, devRobot(e), devScene(e), dm, e->d_dofs.p,
                        (int)n_sets, e->d, e->d_linkQT.p, e->d_objQT.p, e->d_dynXf.p, e->d_dynAabb.p, e->d_linkZ.p, e->d_dynSph.p);
-    HIPCHK(hipEventRecord(ev[1], s));
+    HIPCHK(recEv(e, ev, 1, s));
     HIPCHK(hipEventRecord(e->ev_fk, s));
     e->fk_done = true;
   }
@@ -1468,8 +1479,8 @@ static int enqueueBoth(tohc_engine *e, int filter_mask, int gap, int want_jac, i
   {
     hipStream_t ls = e->lane[slotC % e->n_lanes].stream;
     hipEvent_t *evc = &e->events[(size_t)slotC * NEV];
-    HIPCHK(hipEventRecord(evc[0], ls));
-    HIPCHK(hipEventRecord(evc[1], ls));
+    HIPCHK(recEv(e, evc, 0, ls));
+    HIPCHK(recEv(e, evc, 1, ls));
   }
   rc = narrowPrepare(e, dm, e->d_qchildrenR.p, e->h_qchildrenR, cpC, true, slotC, true, LC);
   if (rc != TOHC_OK) {   // the first pass alone, so that the engine's books stay whole
@@ -1487,7 +1498,7 @@ static int enqueueBoth(tohc_engine *e, int filter_mask, int gap, int want_jac, i
     hipLaunchKernelGGL(k_broadphase_both, dim3((unsigned)LD.blocks), dim3(TOHC_BP_THREADS), 0, LC.s, ba);
     HIPCHK(hipEventRecord(e->ev_fused, LC.s));
     HIPCHK(hipStreamWaitEvent(LD.s, e->ev_fused, 0));
-    HIPCHK(hipEventRecord(LD.ev[2], LD.s));   // the shared launch is booked on the second pass only (cum_ms_broadphase adds the passes up)
+    HIPCHK(recEv(e, LD.ev, 2, LD.s));   // the shared launch is booked on the second pass only (cum_ms_broadphase adds the passes up)
     rc = narrowFinish(e, LD);
     if (rc != TOHC_OK) return rc;
     return narrowFinish(e, LC);
@@ -1511,6 +1522,17 @@ int tohc_enqueue_links_vs_all(tohc_engine *e, int filter_mask, int want_jacobian
 }
 int tohc_enqueue_cast_vs_all(tohc_engine *e, int gap, int want_jacobians, int append) {
   return enqueueRobot(e, gap, 1, -1, want_jacobians, append);
+}
+
+int tohc_set_kernel_timing(tohc_engine *e, int on) {
+  if (!e) return TOHC_E_INVALID;
+  if (!e->pending.empty() || !e->open.empty()) {   // (events of enqueues in flight are read at their sync)
+    HIPCHK(hipSetDevice(e->device));
+    const int rc = syncEngine(e);
+    if (rc != TOHC_OK) return rc;
+  }
+  e->timing = on != 0;
+  return TOHC_OK;
 }
 
 int tohc_sync(tohc_engine *e) {
@@ -1760,8 +1782,8 @@ static int posesQuery(tohc_engine *e, const double *obj_T, const double *cast_T1
   e->staged = false;  // the pose tables below overwrite the staged robot tables
   hipStream_t s = e->stream;
   hipEvent_t *ev = &e->events[(size_t)slot * NEV];
-  HIPCHK(hipEventRecord(ev[0], s));
-  HIPCHK(hipEventRecord(ev[1], s));
+  HIPCHK(recEv(e, ev, 0, s));
+  HIPCHK(recEv(e, ev, 1, s));
   const size_t nobj = e->n_objects, nch = e->n_children;
   HIPCHK(upload(e->d_objQT, obj_T, (size_t)n_sets * nobj * 7, s));
   e->h_qinfoP = queryInfo(e, qch, e->h_child_dynP);
@@ -1866,10 +1888,10 @@ int tohc_continuous_check_trajectory(tohc_engine *e, const double *dofs, int B, 
   DynMap dm = dynMapRobot(e);
   hipStream_t s = e->stream;
   for (auto &ln : e->lane) HIPCHK(hipStreamWaitEvent(s, ln.done, 0));
-  HIPCHK(hipEventRecord(ev[0], s));
+  HIPCHK(recEv(e, ev, 0, s));
   hipLaunchKernelGGL(k_fk, dim3((unsigned)n_sets), dim3(64), (size_t)e->n_links * 7 * sizeof(double), s, devRobot(e), devScene(e), dm, e->d_dofs.p,
                      (int)n_sets, e->d, e->d_linkQT.p, e->d_objQT.p, e->d_dynXf.p, e->d_dynAabb.p);
-  HIPCHK(hipEventRecord(ev[1], s));
+  HIPCHK(recEv(e, ev, 1, s));
   HIPCHK(hipEventRecord(e->ev_fk, s));
   e->fk_done = true;
   CallParams cp;
@@ -1906,8 +1928,8 @@ int tohc_continuous_check_poses(tohc_engine *e, const double *obj_T, int n_steps
   e->staged = false;
   hipStream_t s = e->stream;
   hipEvent_t *ev = &e->events[(size_t)slot * NEV];
-  HIPCHK(hipEventRecord(ev[0], s));
-  HIPCHK(hipEventRecord(ev[1], s));
+  HIPCHK(recEv(e, ev, 0, s));
+  HIPCHK(recEv(e, ev, 1, s));
   const size_t nobj = e->n_objects, nch = e->n_children;
   HIPCHK(upload(e->d_objQT, obj_T, (size_t)n_steps * nobj * 7, s));
   e->h_qinfoP = queryInfo(e, qch, e->h_child_dynP);

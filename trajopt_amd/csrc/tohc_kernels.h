@@ -1663,6 +1663,8 @@ __global__ void __launch_bounds__(BLOCK, TOHC_EPA_WAVES) k_tail_epa(TailArgs ta)
           atomicAdd(&a.dbg[1], wall_clock64() - tw0);
           atomicAdd(&a.dbg[2], clock64() - tc0);
           atomicMax(&a.dbg[3], wall_clock64() - tw0);
+          atomicAdd(&a.dbg[4], (unsigned long long)prof.nslow);
+          atomicAdd(&a.dbg[5], (unsigned long long)prof.nfail);
           for (int k = 0; k < 8; ++k) { atomicAdd(&a.dbg[8 + k], prof.t[k]); atomicAdd(&a.dbg[16 + k], (unsigned long long)prof.n[k]); }
           atomicAdd(&a.dbg[32 + (prof.nsv < 63 ? prof.nsv : 63)], 1ull);
           atomicAdd(&a.dbg[96 + (prof.maxface < 127 ? prof.maxface : 127) / 2], 1ull);

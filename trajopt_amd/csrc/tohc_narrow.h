@@ -72,6 +72,21 @@ struct Grp {
     int oi = __builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, false);
     combineHi(v, i, ov, oi);
   }
+  // bitwise OR over the group's lanes, the result in every lane (the DPP butterfly of argmax)
+  template <int CTRL>
+  static TOHC_DEV unsigned dppOr(unsigned v) { return v | (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false); }
+  static TOHC_DEV unsigned orAll(unsigned v) {
+    if (G >= 2) v = dppOr<0xB1>(v);
+    if (G >= 4) v = dppOr<0x4E>(v);
+    if (G >= 8) v = dppOr<0x141>(v);
+    if (G >= 16) v = dppOr<0x140>(v);
+#pragma unroll
+    for (int m = 16; m < G; m <<= 1) v |= (unsigned)__shfl_xor((int)v, m, G);
+    return v;
+  }
+  static TOHC_DEV unsigned long long orAll64(unsigned long long v) {
+    return ((unsigned long long)orAll((unsigned)(v >> 32)) << 32) | orAll((unsigned)v);
+  }
   // does any lane of the group say so?  (every lane of the group must be active)
   static TOHC_DEV bool any(bool p) {
     const unsigned long long b = __ballot(p);
@@ -93,6 +108,7 @@ struct Grp {
   static float bcast(float v, int) { return v; }
   static void argmax(float &, int &) {}
   static void argmax_hi(float &, int &) {}
+  static unsigned long long orAll64(unsigned long long v) { return v; }
   static bool any(bool p) { return p; }
   static void fence() {}
 #endif
@@ -105,6 +121,7 @@ struct Grp<1> {  // one lane per pair: nothing to exchange
   static TOHC_DEV float bcast(float v, int) { return v; }
   static TOHC_DEV void argmax(float &, int &) {}
   static TOHC_DEV void argmax_hi(float &, int &) {}
+  static TOHC_DEV unsigned long long orAll64(unsigned long long v) { return v; }
   static TOHC_DEV bool any(bool p) { return p; }
   static TOHC_DEV void fence() {}
 };
@@ -846,6 +863,9 @@ TOHC_DEV void gjkMain(const Cvx<G> &A, const Cvx<G> &B, const Xf &tA, const Xf &
 #define TOHC_EPA_SMALL_F 48
 #endif
 #define TOHC_NIL 255
+#ifndef TOHC_EPA_FAST_EXPAND
+#define TOHC_EPA_FAST_EXPAND 1   // 0: every expansion through traverse(), the exact walk (tests compile the host build both ways)
+#endif
 
 // One record per access: a face is read as (normal, distance) = one 16-byte load, its three vertex ids + pass mark
 // = one 4-byte load, its neighbours and their edge numbers = two 4-byte loads -- EPA is a chain of dependent LDS round
@@ -1183,7 +1203,7 @@ struct Gjk2 {
 
 // optional in-kernel profile of EPA (k_epa built with TOHC_EPA_PROF): cycle counts per phase, summed over evaluations
 #if defined(TOHC_EPA_PROF) && defined(__HIPCC__)
-struct EpaProf { unsigned long long t[8]; unsigned n[8]; unsigned maxface, nsv; };
+struct EpaProf { unsigned long long t[8]; unsigned n[8]; unsigned maxface, nsv, nslow, nfail; };
 #define TOHC_PROF_T0(x) unsigned long long x = clock64()
 #define TOHC_PROF_ACC(p, k, x) do { (p).t[k] += clock64() - (x); (p).n[k]++; } while (0)
 #else
@@ -1391,6 +1411,61 @@ struct Epa {
 #undef TOHC_EPA_PUSH
     return ret;
   }
+  // The three expansions of one iteration without the recursion's float work on the walk.  Whether w sees a face,
+  // (dot(n, w) - d) < -eps or not, does not depend on when the walk reaches it: ONE LANE PER FACE settles that for the
+  // whole hull first (a 128-bit mask).  The walk itself is then integer work: a face w sees is entered once (a second
+  // arrival is the reference's `pass` test failing: false), its second neighbour waits on the stack while the first is
+  // followed; a face w does not see is a horizon edge, noted in visiting order, and the walk goes on with the entry on
+  // top of the stack -- whose value sits in a register (the stack in LDS holds every entry; a pop re-reads the one
+  // below off the critical path).  Per face seen: one LDS round trip (its neighbours); per horizon edge: none.
+  // What the walk does not reproduce is WHEN the recursion returns a seen face to the stock, i.e. how many free slots
+  // newface finds at a given horizon edge; so it only answers when the free slots at the start cover the whole horizon
+  // (no edge can run out then), and says EX_SLOW otherwise: the caller runs traverse(), the exact walk, instead.
+  // EX_OK: m->hz[0 .. hnf) = the horizon; (rmLo, rmHi) = the faces the recursion has returned to the stock.
+  enum { EX_OK, EX_FAIL, EX_SLOW };
+  TOHC_DEV int expandFast(unsigned w, unsigned best, uint32_t bfw, uint32_t bew, unsigned long long &rmLo, unsigned long long &rmHi) {
+    const V3 ww = svW(w);
+    unsigned long long vLo = 0, vHi = 0;
+    for (unsigned f = (unsigned)Grp<G>::lane(); f < (unsigned)MEM::kNF; f += G) {
+      if (!onHull(f)) continue;
+      const float *nd = m->fnd[f];
+      const bool beyond = (dot(mk(nd[0], nd[1], nd[2]), ww) - nd[3]) < -0.00001f;   // [epa:800]
+      if (!beyond) { if (MEM::kNF <= 64 || f < 64) vLo |= 1ull << (f & 63u); else vHi |= 1ull << (f - 64); }
+    }
+    vLo = Grp<G>::orAll64(vLo);
+    if (MEM::kNF > 64) vHi = Grp<G>::orAll64(vHi);
+    unsigned long long sLo = best < 64 ? 1ull << best : 0ull, sHi = best < 64 ? 0ull : 1ull << (best - 64);   // entered (best carries `pass` already)
+    const unsigned slots = avail;
+    unsigned sp = 0, top = 0;
+    for (unsigned j = 0; j < 3; ++j) {
+      unsigned cur = byteOf(bfw, j) | (byteOf(bew, j) << 8);
+      for (;;) {
+        const unsigned f = cur & 255u, e = cur >> 8;
+        const unsigned long long bit = 1ull << (f & 63u);
+        const bool hi = MEM::kNF > 64 && f >= 64;   // (a pool of <= 64 faces: the upper words are dead code)
+        if (((hi ? sHi : sLo) & bit) != 0) return EX_FAIL;            // f->pass == pass [epa:797]
+        if (((hi ? vHi : vLo) & bit) != 0) {
+          if (hi) sHi |= bit; else sLo |= bit;
+          const uint32_t fw = m->ff[f], ew = m->fe[f];
+          const unsigned e1 = (e + 1) % 3, e2 = (e + 2) % 3;
+          top = byteOf(fw, e2) | (byteOf(ew, e2) << 8);
+          m->stk[sp++] = (uint16_t)top;                              // (sp < faces entered <= the pool's faces)
+          cur = byteOf(fw, e1) | (byteOf(ew, e1) << 8);
+        } else {
+          if (hnf >= slots) return EX_SLOW;                            // the exact walk decides whether the stock runs out here
+          m->hz[hnf++] = (uint16_t)(f | (e << 7));
+          if (sp == 0) break;
+          cur = top;
+          --sp;
+          top = sp > 0 ? (unsigned)m->stk[sp - 1] : 0u;
+        }
+      }
+    }
+    const unsigned long long bb = 1ull << (best & 63u);
+    rmLo = best < 64 ? sLo & ~bb : sLo;
+    rmHi = best < 64 ? sHi : sHi & ~bb;
+    return EX_OK;
+  }
   // The fan of new faces over the horizon m->hz[0 .. hnf), w = the new vertex: face k = (c[e+1], c[e], w) of horizon
   // entry k [epa:801], bound to the face beyond its edge [epa:804], to its neighbours in the fan [epa:805] and round the
   // end [epa:672]; arrival stamps in horizon order, as the reference's appends.  One lane per new face.
@@ -1495,8 +1570,26 @@ struct Epa {
               TOHC_PROF_T0(te);
               // best's own adjacency is not rewritten while its neighbours are expanded (binds touch the new faces
               // and the faces beyond the horizon), so the words read above stay current
-              for (unsigned j = 0; (j < 3) && valid; ++j) valid &= traverse(pass, w, byteOf(bfw, j), byteOf(bew, j));
+              unsigned long long rmLo = 0, rmHi = 0;
+              const int ex = TOHC_EPA_FAST_EXPAND ? expandFast(w, best, bfw, bew, rmLo, rmHi) : EX_SLOW;
+              if (ex == EX_OK) {   // the faces the recursion has removed, back to the stock
+                hullLo &= ~rmLo; hullHi &= ~rmHi; freeLo |= rmLo; freeHi |= rmHi;
+                hullCount -= (unsigned)(__builtin_popcountll(rmLo) + __builtin_popcountll(rmHi));
+              } else if (ex == EX_FAIL) {
+                valid = false;
+#if defined(TOHC_EPA_PROF) && defined(__HIPCC__)
+                ++prof.nfail;
+#endif
+              } else {
+#if defined(TOHC_EPA_PROF) && defined(__HIPCC__)
+                ++prof.nslow;
+#endif
+                hnf = 0;
+                for (unsigned j = 0; (j < 3) && valid; ++j) valid &= traverse(pass, w, byteOf(bfw, j), byteOf(bew, j));
+              }
+              TOHC_PROF_T0(tm);
               if (valid && (hnf >= 3)) valid = makeHorizon(w);
+              TOHC_PROF_ACC(prof, 7, tm);
               TOHC_PROF_ACC(prof, 2, te);
               if (valid && (hnf >= 3)) {
                 hullToStock(best);
@@ -1621,7 +1714,7 @@ TOHC_DEV bool penStage2(MEM *mem, const Xf &tA, const Xf &tB, Gjk2<G, MEM> &g, b
   e.m = mem;
 #if defined(TOHC_EPA_PROF) && defined(__HIPCC__)
   for (int k = 0; k < 8; ++k) { e.prof.t[k] = 0; e.prof.n[k] = 0; }
-  e.prof.maxface = 0; e.prof.nsv = 0;
+  e.prof.maxface = 0; e.prof.nsv = 0; e.prof.nslow = 0; e.prof.nfail = 0;
 #endif
   TOHC_PROF_T0(ti);
   e.init(limV, limF);

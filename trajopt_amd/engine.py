@@ -90,6 +90,7 @@ SYMBOLS = {
     "tohc_ray_cast_poses_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),   # device pointers
     "tohc_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "tohc_set_capacity": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64]),
+    "tohc_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "tohc_shape_hull": (C.c_int, [_f32p, C.c_int, _i32p, C.c_int, _f32p, C.c_int]),
 }
 
@@ -188,6 +189,10 @@ class Engine:
 
     def get_contact_distance(self):
         return self.lib.tohc_get_contact_distance(self.h)
+
+    def set_kernel_timing(self, on):
+        """Per-stage HIP events between the kernels on / off (tohc_set_kernel_timing): off for the lowest latency."""
+        self._chk(self.lib.tohc_set_kernel_timing(self.h, int(bool(on))))
 
     def set_capacity(self, max_pairs, max_records):
         self._chk(self.lib.tohc_set_capacity(self.h, int(max_pairs), int(max_records)))
