@@ -266,7 +266,7 @@ int tohc_ray_cast_poses_noalloc(tohc_engine *e, const double *d_obj_T, const dou
 int tohc_forward_kinematics(tohc_engine *e, const double *dofs, int n_cfg, double *link_T);
 
 int tohc_get_counters(const tohc_engine *e, tohc_counters *out);
-/* The per-stage times in tohc_counters (cum_ms_fk / _broadphase / _gjk / _epa / _finish) come from HIP events recorded
+/* The per-stage times of tohc_counters -- cum_ms_fk / _broadphase / _gjk / _epa / _finish -- come from HIP events recorded
  * between the kernels of every enqueue; each is a marker packet the next kernel of the stream waits behind.  on = 0 leaves
  * them out (those fields then stay as they are; ms_last_call, the span of the call, is still measured): a single
  * problem's linearization answers ~35 us sooner, a 64-problem step ~2 %.  Default on; TOHC_TIMING=0 in the environment
