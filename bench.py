@@ -651,7 +651,8 @@ def main():
             "ms_per_sqp_linearization_single_problem_host_delivered": lat_ms,
             "ms_per_sqp_linearization_single_problem_device": lat_dev_ms,
             "ms_per_sqp_linearization_single_problem_note": "one problem: tohc_enqueue_linearization + tohc_fetch, DOF vectors staged, per-stage kernel timing "
-                                                            "events off (tohc_set_kernel_timing 0; the timed step above keeps them on: kernel_ms_per_pass)",
+                                                            "events off (tohc_set_kernel_timing 0; the timed step above keeps them on: kernel_ms_per_pass); median of 20 calls after 3: "
+                                                            "from the second linearization of a batch size on, a pass of <= 16 K pairs runs k_gjk<16> (16 lanes per pair)",
             "allgather_slabs_ms": gather_ms, "allgather_slabs_bytes": gather_bytes,
             "ms_continuous_check_trajectory_single_problem": sweep_ms,
             "continuous_check_hits_single_problem": n_sw,

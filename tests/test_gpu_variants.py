@@ -364,3 +364,37 @@ def test_kernel_timing_off_same_slab_and_span(built):
     eng.sync()
     assert eng.counters()["cum_ms_gjk"] > c_on["cum_ms_gjk"]
     eng.close()
+
+
+def test_small_batches_switch_gjk_mapping_same_slab(built):
+    """A pass that held few pairs last time runs k_gjk<16> (16 lanes per pair) instead of k_gjk<1> the next time the same
+    pass is enqueued (tohc_engine::gjk_adapt; TOHC_GJK_ADAPT=0 keeps one lane per pair): the first linearization of an
+    engine and every later one give the same slab as an engine that never switches, and the same work counters."""
+    from trajopt_amd import collision_checker as CC
+    s, rb, static_T, d = synth.config_fullbody_soup(npts=0, n_hulls=512, seed=3)
+    dofs = np.stack([synth.fullbody_trajectory(rb, np.random.default_rng(80 + g), 12) for g in range(2)])
+    out = {}
+    for adapt in ("1", "0"):
+        old = os.environ.get("TOHC_GJK_ADAPT")
+        os.environ["TOHC_GJK_ADAPT"] = adapt
+        try:
+            cc = CC.HIPCollisionChecker(s, static_T, None)
+        finally:
+            if old is None:
+                os.environ.pop("TOHC_GJK_ADAPT", None)
+            else:
+                os.environ["TOHC_GJK_ADAPT"] = old
+        cc.SetRobot(rb); cc.SetContactDistance(d)
+        eng = cc.eng
+        eng.stage_dofs(dofs, 2, 12)
+        runs = []
+        for _ in range(3):
+            eng.enqueue_linearization(-1, 1, True)
+            rec, g = eng.fetch()
+            c = eng.counters()
+            runs.append((rec.tobytes(), g.tobytes(), tuple(c[k] for k in ("pair_evals", "gjk_evals", "epa_evals", "contacts"))))
+        assert len(rec) > 100 and 0 < c["gjk_evals"] <= 16384   # (few enough pairs for the switch)
+        out[adapt] = runs
+        eng.close()
+    for r in out["1"] + out["0"]:
+        assert r == out["0"][0]

@@ -152,12 +152,16 @@ struct tohc_engine {
   // kernel time per step) but the step is longer (4.83 vs 4.55 ms), because a shared tail cannot start before BOTH heads
   // have finished and so no longer overlaps with the other pass's broadphase / GJK.
   int max_open = 1;
+  // tohc_enqueue_linearization hands both passes' heads to the GPU before the first pass's tail (TOHC_HEADS_FIRST=0: pass by
+  // pass).  The host needs ~0.1 ms to submit one pass's ten launches and event operations; for a single problem, whose
+  // kernels last 10 - 100 us each, the second pass's head otherwise starts that much later than it could.
+  int heads_first = 1;
   hipStream_t tail_stream = nullptr;
   hipEvent_t tail_ranged = nullptr;  // recorded after the latest k_tail_range
   bool have_ranged = false;
   bool fk_done = false;
   DBuf<unsigned long long> d_dbg;   // TOHC_EPA_PROF builds only
-  DBuf<Counters> d_cnt;            // [RING]
+  DBuf<Counters> d_cnt;            // [1 + RING]: element 0 holds the slab's record counter (d_nrec), slot i is element 1 + i -- one D2H copy brings both
   DBuf<unsigned int> d_rec_base;   // [RING] first record of each enqueue (k_range)
   DBuf<tohc_record> d_records, d_sorted;
   DBuf<double> d_gsorted;
@@ -170,15 +174,14 @@ struct tohc_engine {
   bool host_sort = false;   // TOHC_HOST_SORT=1: order the slab on the host (the path taken anyway beyond the key's limits)
   HBuf<tohc_record> h_records, h_sorted;
   HBuf<double> h_grads, h_gsorted;
-  HBuf<Counters> h_cnt;            // [RING]
+  HBuf<Counters> h_cnt;            // [1 + RING], the same layout
   size_t max_pairs = (size_t)1 << 22, max_records = (size_t)1 << 18;
   tohc_counters counters;
   // enqueue ring: every enqueue since the last sync has its own device counter slot and event set
-  struct Pending { int slot; int64_t aabb_tests; };
+  struct Pending { int slot; int64_t aabb_tests; int kind = -1; int units = 0; };   // kind: 0 discrete / 1 cast pass of the narrowphase pipeline, -1 anything else
   std::vector<Pending> pending;
   std::vector<hipEvent_t> events;   // RING * NEV
-  DBuf<unsigned int> d_nrec;        // shared record counter
-  HBuf<unsigned int> h_nrec;
+  struct { unsigned int *p = nullptr; } d_nrec, h_nrec;   // shared record counter: the first word of d_cnt / h_cnt
   HBuf<double> h_dofs;              // pinned staging of the DOF vectors
   int staged_B = 0, staged_T = 0;
   bool staged = false;
@@ -213,6 +216,16 @@ struct tohc_engine {
   // what the current slab holds, pass by pass (enqueue calls): the hinge assembly takes one discrete and / or one cast pass
   int slab_B = 0, slab_disc_passes = 0, slab_cast_passes = 0, slab_gap = 0;
   int gjk_group = 1;  // lanes per pair in k_gjk: 1 (default), 16 or 64 (TOHC_GJK_GROUP)
+  // Small batches (TOHC_GJK_ADAPT=0: off).  One lane per pair is the mapping for a full chip: its hull scans are chains of L2
+  // round trips that only many resident wavefronts hide.  One problem alone (config 4: ~7 K pairs per pass, 116 wavefronts)
+  // leaves the chip empty and waits for every one of them; with 16 lanes per pair (hull vertices in registers, DPP
+  // arg-max, no memory access inside the loop) the same list answers sooner -- measured on config 4, one problem:
+  // 0.70 -> 0.64 ms host-delivered, two problems 0.534 -> 0.507 ms per step, three 0.60 -> 0.66 with 22 K pairs in the cast pass (gpurun_out/s4_*, s5_*).  How
+  // many pairs a pass holds is only known on the device, so the choice follows the LAST pass of the same kind and the
+  // same number of units (an SQP solve linearizes the same problem again and again; syncEngineImpl notes the counts);
+  // without such a pass: one lane per pair.  Results do not depend on it (test_engine_variants_compute_the_same_slab).
+  int gjk_adapt = 1;
+  struct GjkHint { int units = -1; unsigned int pairs = 0; } gjk_hint[2];   // [cast]
   int pen_group = 1;   // lanes per pair in k_pen: 1, or 4 (hull vertices in registers; TOHC_PEN_GROUP=4: measured no faster, GJK2's LDS bookkeeping dominates)
   int epa_block = 64;  // threads per k_epa block (TOHC_EPA_BLOCK = 16 or 64)
   bool timing = true;  // per-stage timing events between the kernels (recEv)
@@ -357,6 +370,7 @@ int tohc_create(tohc_engine **out, int device) {
     return TOHC_E_HIP;
   }
   if (const char *mt = getenv("TOHC_MERGE_TAIL")) e->max_open = atoi(mt) != 0 ? TOHC_MAX_HEADS : 1;
+  if (const char *hf = getenv("TOHC_HEADS_FIRST")) e->heads_first = atoi(hf) != 0;
   if (const char *eb = getenv("TOHC_EPA_BLOCK")) e->epa_block = atoi(eb) == 16 ? 16 : 64;
   if (const char *ub = getenv("TOHC_UNIT_BP")) e->unit_broadphase = std::max(atoi(ub), 0);
   if (const char *tm = getenv("TOHC_TIMING")) e->timing = atoi(tm) != 0;
@@ -368,12 +382,15 @@ int tohc_create(tohc_engine **out, int device) {
   if (const char *hs = getenv("TOHC_HOST_SORT")) e->host_sort = atoi(hs) != 0;
   e->gjk_group = e->group == 64 ? 64 : 1;
   if (const char *gg = getenv("TOHC_GJK_GROUP")) { int v = atoi(gg); if (v == 1 || v == 16 || v == 64) e->gjk_group = v; }
+  if (const char *ga = getenv("TOHC_GJK_ADAPT")) e->gjk_adapt = atoi(ga) != 0;
   e->breaking = (float)(2.001 * (double)e->d);
   e->events.resize((size_t)RING * NEV);
   for (auto &ev : e->events)
     if (hipEventCreate(&ev) != hipSuccess) { tohc_destroy(e); return TOHC_E_HIP; }
-  if (e->d_cnt.reserve(RING) != hipSuccess || e->d_rec_base.reserve(RING) != hipSuccess || e->h_cnt.reserve(RING) != hipSuccess || e->d_nrec.reserve(1) != hipSuccess ||
-      e->h_nrec.reserve(1) != hipSuccess || hipMemset(e->d_nrec.p, 0, sizeof(unsigned int)) != hipSuccess) { tohc_destroy(e); return TOHC_E_HIP; }
+  if (e->d_cnt.reserve(1 + RING) != hipSuccess || e->d_rec_base.reserve(RING) != hipSuccess || e->h_cnt.reserve(1 + RING) != hipSuccess ||
+      hipMemset(e->d_cnt.p, 0, sizeof(Counters)) != hipSuccess) { tohc_destroy(e); return TOHC_E_HIP; }
+  e->d_nrec.p = reinterpret_cast<unsigned int *>(e->d_cnt.p);
+  e->h_nrec.p = reinterpret_cast<unsigned int *>(e->h_cnt.p);
   *e->h_nrec.p = 0;   // a fetch before the first enqueue reads this word
   if (scratchInit(device) != hipSuccess) { tohc_destroy(e); return TOHC_E_HIP; }
   *out = e;
@@ -893,9 +910,8 @@ static int syncEngineImpl(tohc_engine *e) {
   for (auto &ln : e->lane) HIPCHK(hipStreamSynchronize(ln.stream));
   HIPCHK(hipStreamSynchronize(e->tail_stream));
   if (e->pending.empty()) { HIPCHK(hipStreamSynchronize(s)); return TOHC_OK; }
-  for (const auto &pd : e->pending)   // only the slots in use: a Counters is 2 KB now
-    HIPCHK(hipMemcpyAsync(e->h_cnt.p + pd.slot, e->d_cnt.p + pd.slot, sizeof(Counters), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(e->h_nrec.p, e->d_nrec.p, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+  // ONE copy: the record counter (element 0) and the slots in use, which are 0 .. pending - 1 (a Counters is 2 KB)
+  HIPCHK(hipMemcpyAsync(e->h_cnt.p, e->d_cnt.p, (1 + e->pending.size()) * sizeof(Counters), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   bool overflow = false;
   unsigned int worst_pairs = 0;
@@ -904,7 +920,7 @@ static int syncEngineImpl(tohc_engine *e) {
   c.gjk_iters = c.pen_supports = c.epa_supports = c.epa_redone = 0;
   c.ms_last_call = 0;
   for (const auto &pd : e->pending) {
-    const Counters &k = e->h_cnt.p[pd.slot];
+    const Counters &k = e->h_cnt.p[1 + pd.slot];
     const unsigned int segCap = (unsigned int)(e->max_pairs / TOHC_NSHARD);
     unsigned int np = 0, ne = 0, ng = 0;
     int64_t gi = 0, ps = 0, es = 0, er = 0;
@@ -919,6 +935,7 @@ static int syncEngineImpl(tohc_engine *e) {
     c.cum_gjk_iters += gi; c.cum_pen_supports += ps; c.cum_epa_supports += es;
     c.epa_redone += er; c.cum_epa_redone += er;
     worst_pairs = std::max(worst_pairs, ng);
+    if (pd.kind >= 0) { e->gjk_hint[pd.kind].units = pd.units; e->gjk_hint[pd.kind].pairs = ng; }
     c.aabb_tests += pd.aabb_tests; c.pair_evals += np; c.epa_evals += ne; c.gjk_evals += ng;
     c.cum_aabb_tests += pd.aabb_tests; c.cum_pair_evals += np; c.cum_epa_evals += ne; c.cum_gjk_evals += ng;
     float ms[NEV - 1] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -987,6 +1004,9 @@ static int64_t countAabbTests(const tohc_engine *e, const std::vector<int> &qchi
 // broadphase -> GJK -> EPA for one enqueue; `ev` = this enqueue's events [2..5] are recorded here
 #ifndef TOHC_GJK_GRID
 #define TOHC_GJK_GRID 16384   // lane-per-pair blocks of one wavefront: many small blocks, so the hardware dispatcher balances the uneven runs (4096: 0.51 ms per launch, 16384: 0.37)
+#endif
+#ifndef TOHC_GJK16_MAX_PAIRS
+#define TOHC_GJK16_MAX_PAIRS 16384   // k_gjk<16> instead of k_gjk<1> up to this many pairs in the pass (tohc_engine::gjk_adapt)
 #endif
 #ifndef TOHC_DIST_BLOCKS
 #define TOHC_DIST_BLOCKS 256   // blocks of k_tail_epa that run the Distance fall-back
@@ -1086,7 +1106,7 @@ static int launchTail(tohc_engine *e) {
 // books, the tail).
 struct NarrowLaunch {
   int slot = 0, laneIdx = 0, nQ = 0;
-  bool wantJ = false, noSlab = false, append = false, robotMode = false, unitAll = false;
+  bool wantJ = false, noSlab = false, append = false, robotMode = false, unitAll = false, gjk16 = false;
   CallParams cp;
   hipStream_t s = nullptr;
   hipEvent_t *ev = nullptr;
@@ -1122,13 +1142,18 @@ static int narrowPrepare(tohc_engine *e, const DynMap &dm, const int *d_qchildre
   tohc_engine::Lane &ln = e->lane[laneIdx];
   hipStream_t s = ln.stream;
   hipEvent_t *ev = &e->events[(size_t)slot * NEV];
-  HIPCHK(hipStreamWaitEvent(s, e->ev_fk, 0));   // pose tables of this call (FK / k_dyn_children on the main stream)
   // a new slab starts only after everything that wrote the old one
   if (!append && slot > 0)
     for (auto &other : e->lane)
       if (&other != &ln) HIPCHK(hipStreamWaitEvent(s, other.done, 0));
-  HIPCHK(hipMemsetAsync(e->d_cnt.p + slot, 0, sizeof(Counters), s));
-  if (!append) HIPCHK(hipMemsetAsync(e->d_nrec.p, 0, sizeof(unsigned int), s));
+  // the pass's counters, and the record counter when a slab starts (element 0 of d_cnt: with slot 0 one fill clears both).
+  // Before the wait for FK: nothing FK writes is touched, so the fills run beside it instead of after it.
+  if (!append && slot == 0) HIPCHK(hipMemsetAsync(e->d_cnt.p, 0, 2 * sizeof(Counters), s));
+  else {
+    HIPCHK(hipMemsetAsync(e->d_cnt.p + 1 + slot, 0, sizeof(Counters), s));
+    if (!append) HIPCHK(hipMemsetAsync(e->d_nrec.p, 0, sizeof(unsigned int), s));
+  }
+  HIPCHK(hipStreamWaitEvent(s, e->ev_fk, 0));   // pose tables of this call (FK / k_dyn_children on the main stream)
   cp.seg_cap = (unsigned int)(e->max_pairs / TOHC_NSHARD); cp.max_records = (unsigned int)e->max_records;
   cp.dbg_max_iter = getenv("TOHC_DBG_MAXITER") ? atoi(getenv("TOHC_DBG_MAXITER")) : 1000;
   cp.epa_small_v = e->epa_small_v; cp.epa_small_f = e->epa_small_f;
@@ -1137,7 +1162,11 @@ static int narrowPrepare(tohc_engine *e, const DynMap &dm, const int *d_qchildre
   HIPCHK(ln.pairs.reserve(qcap)); HIPCHK(ln.epaq.reserve(qcap)); HIPCHK(ln.hits.reserve(qcap));
   HIPCHK(ln.penq.reserve((size_t)(cp.seg_cap / TOHC_PEN_DIV) * TOHC_NSHARD));
   HIPCHK(ln.distq.reserve(qcap));
-  cp.gjk_split = e->gjk_group == 1 ? e->gjk_split : 0;
+  {
+    const tohc_engine::GjkHint &hint = e->gjk_hint[cp.cast ? 1 : 0];
+    L.gjk16 = e->gjk_group == 16 || (e->gjk_group == 1 && e->gjk_adapt && hint.units == cp.n_cast_sets && hint.pairs <= TOHC_GJK16_MAX_PAIRS);
+  }
+  cp.gjk_split = (e->gjk_group == 1 && !L.gjk16) ? e->gjk_split : 0;
   if (cp.gjk_split > 0) HIPCHK(ln.contq.reserve((size_t)(cp.seg_cap / TOHC_CONT_DIV) * TOHC_NSHARD));
   if (e->defer_exact) HIPCHK(ln.cands.reserve(qcap));
 #if defined(TOHC_EPA_PROF)
@@ -1158,7 +1187,7 @@ static int narrowPrepare(tohc_engine *e, const DynMap &dm, const int *d_qchildre
   a.linkQT = robotMode ? e->d_linkQT.p : nullptr;
   a.linkZ = robotMode ? e->d_linkZ.p : nullptr;
   a.dofs = robotMode ? e->d_dofs.p : nullptr;
-  a.pairs = ln.pairs.p; a.cands = ln.cands.p; a.epaq = ln.epaq.p; a.penq = ln.penq.p; a.distq = ln.distq.p; a.contq = ln.contq.p; a.hits = ln.hits.p; a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p; a.rec_base = e->d_rec_base.p + slot;
+  a.pairs = ln.pairs.p; a.cands = ln.cands.p; a.epaq = ln.epaq.p; a.penq = ln.penq.p; a.distq = ln.distq.p; a.contq = ln.contq.p; a.hits = ln.hits.p; a.cnt = e->d_cnt.p + 1 + slot; a.n_records = e->d_nrec.p; a.rec_base = e->d_rec_base.p + slot;
   a.records = e->d_records.p; a.grads = e->d_grads.p; a.dbg = e->d_dbg.p;
   L.cp = cp;
   memset(&L.ca, 0, sizeof L.ca);
@@ -1206,7 +1235,20 @@ static int narrowBroadphase(tohc_engine *e, NarrowLaunch &L) {
   }
   return TOHC_OK;
 }
-static int narrowFinish(tohc_engine *e, NarrowLaunch &L) {
+// every open pass gets a tail of its own, in enqueue order (launchTail with several passes open makes ONE shared tail)
+static int launchTailsEach(tohc_engine *e) {
+  std::vector<tohc_engine::OpenHead> all;
+  all.swap(e->open);
+  int rc = TOHC_OK;
+  for (const auto &h : all) {
+    e->open.assign(1, h);
+    const int r = launchTail(e);
+    if (r != TOHC_OK && rc == TOHC_OK) rc = r;
+  }
+  return rc;
+}
+// holdTail: the pass stays open; the caller launches its tail (launchTailsEach / launchTail)
+static int narrowFinish(tohc_engine *e, NarrowLaunch &L, bool holdTail = false) {
   const CallParams &cp = L.cp;
   hipStream_t s = L.s;
   hipEvent_t *ev = L.ev;
@@ -1219,7 +1261,7 @@ static int narrowFinish(tohc_engine *e, NarrowLaunch &L) {
     }
     HIPCHK(recEv(e, ev, 3, s));
     const int gridN = 256 * 8;
-    if (e->gjk_group == 1) {  // one lane per pair, one wavefront per block
+    if (e->gjk_group == 1 && !L.gjk16) {  // one lane per pair, one wavefront per block
       if (cp.cast) hipLaunchKernelGGL((k_gjk<1, true, 64>), dim3(TOHC_GJK_GRID), dim3(64), 0, s, a);
       else hipLaunchKernelGGL((k_gjk<1, false, 64>), dim3(TOHC_GJK_GRID), dim3(64), 0, s, a);
       if (cp.gjk_split > 0) {
@@ -1243,12 +1285,13 @@ static int narrowFinish(tohc_engine *e, NarrowLaunch &L) {
   tohc_engine::Pending pd;
   pd.slot = L.slot;
   pd.aabb_tests = countAabbTests(e, *L.h_qchildren, cp);
+  pd.kind = cp.cast ? 1 : 0; pd.units = cp.n_cast_sets;
   e->pending.push_back(pd);
   e->sorted_valid = false;
   if (!L.append || L.noSlab) { e->last_robot_mode = L.robotMode; e->last_want_jac = L.wantJ; }
   if (!L.append) e->slab_state = 0;   // a new slab is being filled
   e->last_T = cp.T;
-  if ((int)e->open.size() >= e->max_open) return launchTail(e);
+  if (!holdTail && (int)e->open.size() >= e->max_open) return launchTail(e);
   return TOHC_OK;
 }
 static int launchNarrow(tohc_engine *e, const DynMap &dm, const int *d_qchildren, const std::vector<int> &h_qchildren, CallParams cp,
@@ -1276,7 +1319,7 @@ static int launchSweep(tohc_engine *e, const DynMap &dm, const int *d_qchildren,
   for (auto &other : e->lane)
     if (&other != &ln) HIPCHK(hipStreamWaitEvent(s, other.done, 0));
   if (e->slab_read_pending) HIPCHK(hipStreamWaitEvent(s, e->ev_slab_read, 0));   // k_sweep writes records itself
-  HIPCHK(hipMemsetAsync(e->d_cnt.p + slot, 0, sizeof(Counters), s));
+  HIPCHK(hipMemsetAsync(e->d_cnt.p + 1 + slot, 0, sizeof(Counters), s));
   HIPCHK(hipMemsetAsync(e->d_nrec.p, 0, sizeof(unsigned int), s));
   cp.seg_cap = (unsigned int)(e->max_pairs / TOHC_NSHARD); cp.max_records = (unsigned int)e->max_records;
   cp.dbg_max_iter = 1000;
@@ -1303,7 +1346,7 @@ static int launchSweep(tohc_engine *e, const DynMap &dm, const int *d_qchildren,
     memset(&a, 0, sizeof a);
     a.sc = devScene(e); a.dm = dm; a.rb = devRobot(e); a.cp = cp;
     a.dynXf0 = e->d_dynXf.p; a.dynXf1 = e->d_dynXf.p;
-    a.cnt = e->d_cnt.p + slot; a.n_records = e->d_nrec.p; a.rec_base = e->d_rec_base.p + slot; a.records = e->d_records.p;
+    a.cnt = e->d_cnt.p + 1 + slot; a.n_records = e->d_nrec.p; a.rec_base = e->d_rec_base.p + slot; a.records = e->d_records.p;
     sa.qchildren = d_qchildren; sa.nQ = nQ; sa.dynAabb0 = e->d_dynAabb.p;
     sa.grow = 0.0011f + 4.0e-3f * discMax;
     hipLaunchKernelGGL(k_sweep, dim3((unsigned)blocks), dim3(64), 0, s, sa);
@@ -1499,9 +1542,12 @@ static int enqueueBoth(tohc_engine *e, int filter_mask, int gap, int want_jac, i
     HIPCHK(hipEventRecord(e->ev_fused, LC.s));
     HIPCHK(hipStreamWaitEvent(LD.s, e->ev_fused, 0));
     HIPCHK(recEv(e, LD.ev, 2, LD.s));   // the shared launch is booked on the second pass only (cum_ms_broadphase adds the passes up)
-    rc = narrowFinish(e, LD);
+    const bool headsFirst = e->heads_first && e->max_open == 1;
+    rc = narrowFinish(e, LD, headsFirst);
     if (rc != TOHC_OK) return rc;
-    return narrowFinish(e, LC);
+    rc = narrowFinish(e, LC, headsFirst);
+    if (rc != TOHC_OK || !headsFirst) return rc;
+    return launchTailsEach(e);
   }
   rc = narrowBroadphase(e, LD);
   if (rc == TOHC_OK) rc = narrowFinish(e, LD);
