@@ -270,6 +270,7 @@ static hipError_t quiesce(tohc_engine *e) {
   if (e->tail_stream) { hipError_t r = hipStreamSynchronize(e->tail_stream); if (r != hipSuccess) return r; }
   if (e->hinge_stream) { hipError_t r = hipStreamSynchronize(e->hinge_stream); if (r != hipSuccess) return r; }
   e->fk_done = false;
+  e->gjk_hint[0] = e->gjk_hint[1] = tohc_engine::GjkHint();   // (a new scene, robot, distance or matrix: pair counts of the old one say nothing)
   return hipStreamSynchronize(e->stream);
 }
 #define HIPCHK(call)                                                                                         \
