@@ -40,6 +40,7 @@ long g_iter_hist[64];
 long g_epa_hist[2];
 long g_epa_redone;
 long g_pre[8];
+int g_log_q = -1, g_log_x = -1;   // (EMU_EPA_LOG: scene-wide child numbers of the pair being evaluated)
 bool pairEval(World *w, const Cvx<1> &A, const Xf &tA, const Cvx<1> &B, const Xf &tB, ora_contact *c) {
   const float md = pairMaxDist2<1>(A, B, w->breaking);
   GjkState st;
@@ -107,7 +108,7 @@ bool pairEval(World *w, const Cvx<1> &A, const Xf &tA, const Cvx<1> &B, const Xf
       V3 dir = tA.o - tB.o, ww;
       float ov = 0;
       if (len2(dir) > 1e-12f) { dir = vdiv(dir, len(dir)); sepAxisBeyond<1>(A, B, tA, tB, dir, 0.f, ww); ov = -dot(dir, ww); }
-      if (es.epa_calls != prevCalls) fprintf(f, "%ld %d %d %d %d %g %g\n", es.epa_iters - prevIt, A.kind, A.n, B.kind, B.n, (double)st.distance, (double)ov), fflush(f);
+      if (es.epa_calls != prevCalls) fprintf(f, "%ld %d %d %d %d %g %g %d %d\n", es.epa_iters - prevIt, A.kind, A.n, B.kind, B.n, (double)st.distance, (double)ov, g_log_q, g_log_x), fflush(f);
       prevIt = es.epa_iters; prevCalls = es.epa_calls;
     }
   }
@@ -203,6 +204,7 @@ int emu_links_vs_all(void *h, const double *objT7, const int *q, int nq, int fil
           ora_contact c;
           memset(&c, 0, sizeof c);
           bool kept;
+          g_log_q = w->off[Q] + qc; g_log_x = w->off[X] + xc;
           if (w->compound[X]) { kept = pairEval(w, cx, tx, cq, tq, &c); c.objA = X; c.childA = xc; c.objB = Q; c.childB = qc; }
           else { kept = pairEval(w, cq, tq, cx, tx, &c); c.objA = Q; c.childA = qc; c.objB = X; c.childB = xc; }
           if (kept) { if (n < cap) out[n] = c; ++n; }
@@ -245,6 +247,7 @@ int emu_cast_vs_all(void *h, const double *objT7, const int *q, int nq, const do
             w->pair_evals++;   // as k_gjk does: the evaluation ends at the reference's child-box test
             continue;
           }
+          g_log_q = w->off[Q] + qc; g_log_x = w->off[X] + xc;
           if (w->compound[X]) { kept = pairEval(w, cx, tx, cq, tf0, &c); c.objA = X; c.childA = xc; c.objB = Q; c.childB = qc; castFirst = false; }
           else { kept = pairEval(w, cq, tf0, cx, tx, &c); c.objA = Q; c.childA = qc; c.objB = X; c.childB = xc; castFirst = true; }
           if (!kept) continue;
