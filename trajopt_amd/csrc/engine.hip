@@ -129,6 +129,7 @@ struct tohc_engine {
     hipEvent_t done = nullptr;       // recorded after the lane's latest k_finish
     hipEvent_t head_done = nullptr;  // recorded after the lane's latest k_gjk: the tail may start on that pass's queues
     DBuf<PairRec> pairs, cands;
+    DBuf<float> castAabb;            // [sets][moving children][6]: second boxes of the lane's cast pass (k_cast_boxes)
     DBuf<EpaRec> epaq;
     DBuf<PenRec> penq;
     DBuf<unsigned int> distq;
@@ -1200,6 +1201,12 @@ static int narrowPrepare(tohc_engine *e, const DynMap &dm, const int *d_qchildre
     CullArgs &ca = L.ca;
     ca.a = a; ca.qchildren = d_qchildren; ca.nQ = nQ;
     ca.dynAabb0 = e->d_dynAabb.p; ca.dynAabb1 = sep1 ? e->d_dynAabb1.p : e->d_dynAabb.p;
+    if (cp.cast && dm.n_dyn_children > 0) {   // the swept children's second boxes as the reference rounds them (k_cast_boxes)
+      const size_t tot = (size_t)cp.n_cast_sets * dm.n_dyn_children;
+      HIPCHK(ln.castAabb.reserve((size_t)std::max<int64_t>(e->last_sets, 1) * dm.n_dyn_children * 6));
+      hipLaunchKernelGGL(k_cast_boxes, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, a.sc, dm, cp, a.dynXf0, a.dynXf1, ln.castAabb.p);
+      ca.dynAabb1 = ln.castAabb.p;
+    }
     ca.dynSph0 = e->d_dynSph.p;
     ca.pretest = e->pretest;
     ca.defer_exact = 0;

@@ -485,6 +485,29 @@ __device__ __forceinline__ void loadSideU(const NarrowArgs &a, int child, int se
   }
 }
 
+// k_cast_boxes: the second box of a swept child, as the reference makes it.  CastHullShape::getAabb
+// (bullet_collision_checker.cpp:850-856) joins the shape's box at t with its box at t * m_t01, and m_t01 = tf0^-1 * tf1 is
+// rounded: t * m_t01 is tf1 to an ulp or two, not tf1.  The box of the pose table's tf1 (k_fk / k_dyn_children) differs
+// from it by as little -- and flipped one box test in 22.6 million on config 4 (a pair evaluation the oracle counted and
+// the engine did not; no contact can hang on it, both boxes are grown by d).  One thread per (cast unit, moving child):
+// out[set1][slot] = box at tf0 * (tf0^-1 * tf1), read by the broadphase kernels in place of the table's box at set1.
+__global__ void __launch_bounds__(256) k_cast_boxes(DevScene sc, DynMap dm, CallParams cp, const float *__restrict__ dynXf0, const float *__restrict__ dynXf1,
+                                                    float *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t ndc = (size_t)dm.n_dyn_children;
+  if (i >= (size_t)cp.n_cast_sets * ndc) return;
+  const int cs = cp.unit_base + (int)(i / ndc), slot = (int)(i % ndc);
+  int set0, set1;
+  castSets(cp, cs, set0, set1);
+  const Xf t0 = ldXf(dynXf0 + ((size_t)set0 * ndc + slot) * 12), t1 = ldXf(dynXf1 + ((size_t)set1 * ndc + slot) * 12);
+  const Xf tw1 = xfMul(t0, xfInverseTimes(t0, t1));
+  const int sh = sc.child_shape[dm.dyn_children[slot]];
+  const Aabb b = shapeAabb(mk(sc.shape_lmin[3 * sh], sc.shape_lmin[3 * sh + 1], sc.shape_lmin[3 * sh + 2]),
+                           mk(sc.shape_lmax[3 * sh], sc.shape_lmax[3 * sh + 1], sc.shape_lmax[3 * sh + 2]), tw1, cp.d);
+  float *ob = out + ((size_t)set1 * ndc + slot) * 6;
+  ob[0] = b.lo.x; ob[1] = b.lo.y; ob[2] = b.lo.z; ob[3] = b.hi.x; ob[4] = b.hi.y; ob[5] = b.hi.z;
+}
+
 // -----------------------------------------------------------------------------------------------------------------
 // k_broadphase: ONE WAVEFRONT per (unit, query child).  Filters follow CollisionCollector::needsCollision
 // (bullet_collision_checker.cpp:409-413) and btSingleContactCallback::process (btCollisionWorld.cpp:1129-1137); the
