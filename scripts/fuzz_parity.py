@@ -13,6 +13,7 @@ Kinds of case (seed % 6):
   4  ContinuousCheckTrajectory on explicit poses (k_sweep), 5 pose sets, d = 0 and 0.05: hit set, fraction, normal, point
      bit for bit (oracle in portable-trig mode, as in tests/test_gpu_parity.py)
   5  RayCastCollision, 2000 rays: fractions bit for bit
+Kinds 0 - 3 also hold the engine's pair-evaluation count (the unit of the headline metric) equal to the oracle's.
 The oracle is the checker, never the thing measured.  A mismatch is recorded with its seed and the run goes on.
 """
 import argparse
@@ -60,11 +61,18 @@ def one_case(eng, seed):
                 eng.set_contact_distance(d)
                 w.set_contact_distance(d)
                 rec = eng.links_vs_all_poses(sets, robot); book()
+                pe_d = int(eng.counters()["pair_evals"])
                 recc = eng.cast_vs_all_poses(sets, robot, T1); book()
+                pe_c = int(eng.counters()["pair_evals"])
+                c0 = w.counter(0)
                 for k in range(nsets):
                     util.assert_same_contacts(util.records_to_contacts(rec[rec["problem"] == k]), w.links_vs_all(sets[k], robot), "disc set %d d=%g" % (k, d))
+                c1 = w.counter(0)
+                for k in range(nsets):
                     util.assert_same_contacts(util.records_to_contacts(recc[recc["problem"] == k]),
                                               w.cast_vs_all(sets[k], robot, sets[k][robot], T1[k]), "cast set %d d=%g" % (k, d))
+                # the unit of the headline metric: both sides count the same pair evaluations (box-cull survivors)
+                assert (pe_d, pe_c) == (c1 - c0, w.counter(0) - c1), "pair evaluations differ d=%g: engine %s oracle %s" % (d, (pe_d, pe_c), (c1 - c0, w.counter(0) - c1))
                 ava = eng.all_vs_all_poses(sets[0]); book()
                 util.assert_same_contacts(util.records_to_contacts(ava), w.all_vs_all(sets[0]), "all-vs-all d=%g" % d)
                 stats["contacts"] += len(rec) + len(recc) + len(ava)
@@ -129,6 +137,8 @@ def one_case(eng, seed):
             eng.enqueue_linearization(-1, 1, True)
             rec, g = eng.fetch()
             book()
+            pe = int(eng.counters()["pair_evals"])
+            c0 = w.counter(0)
             for b in range(Bp):
                 sel = rec["problem"] == b
                 disc = sel & (rec["cctype"] == 0)
@@ -137,6 +147,7 @@ def one_case(eng, seed):
                 util.assert_same_linearization(rec[disc], g[disc], orec, og, "robot disc b=%d d=%g" % (b, d))
                 orec, og = w.linearize(rb, static_T, dofs[b], cast=True)
                 util.assert_same_linearization(rec[cast], g[cast], orec, og, "robot cast b=%d d=%g" % (b, d))
+            assert pe == w.counter(0) - c0, "pair evaluations differ: engine %d oracle %d" % (pe, w.counter(0) - c0)
             stats["contacts"] += len(rec)
         finally:
             w.close()
