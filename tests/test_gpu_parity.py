@@ -788,3 +788,31 @@ def test_cast_cull_box_rounds_like_the_reference(built):
         util.assert_same_linearization(rec, g, orec, og, "cast unit %d of problem 18" % t)
     w.close()
     eng.close()
+
+
+def test_bench_workload_whole_problems_vs_oracle(built):
+    """bench.py's default workload (config 4 as BASELINE.md has it: 4096 hulls of 42 vertices), three whole problems of 100
+    timesteps in one call, discrete + cast with gradient rows: EVERY record against the oracle and the pair-evaluation count
+    of the headline metric equal to the oracle's.  (scripts/check_bench_step.py does this for all 64 problems of the timed
+    step on 14 cores; profiles/r03_check_*.json.)"""
+    import bench
+    s, rb, static_T, d, cc, dofs = bench.build_world("fullbody42", 0, 1, 3)
+    eng = cc.eng
+    eng.stage_dofs(dofs, 3, 100)
+    eng.enqueue_linearization(-1, 1, True)
+    rec, g = eng.fetch()
+    pe = eng.counters()["pair_evals"]
+    w = B.oracle_world(s, cap=1 << 18)
+    w.set_contact_distance(d)
+    w.set_allowed(cc.allowed)
+    c0 = w.counter(0)
+    for b in range(3):
+        sel = rec["problem"] == b
+        disc, cast = sel & (rec["cctype"] == 0), sel & (rec["cctype"] != 0)
+        orec, og = w.linearize(rb, static_T, dofs[b])
+        util.assert_same_linearization(rec[disc], g[disc], orec, og, "bench problem %d discrete" % b)
+        orec, og = w.linearize(rb, static_T, dofs[b], cast=True)
+        util.assert_same_linearization(rec[cast], g[cast], orec, og, "bench problem %d cast" % b)
+    assert pe == w.counter(0) - c0 and len(rec) > 1000
+    w.close()
+    eng.close()
