@@ -1,7 +1,8 @@
 // engine.hip -- libtrajopt_hipcc.so: the C-ABI of include/trajopt_hipcc.h and the gfx950 kernels behind it.
 //
 // Pipeline of one batch call (all on the engine's own stream, nothing allocates after warm-up):
-//   per pass:  k_fk -> k_broadphase -> k_gjk                       (a pass = one enqueue: discrete or cast)
+//   per pass:  k_fk -> (k_cast_boxes) -> k_broadphase -> k_exact -> k_gjk -> k_gjk_cont    (a pass = one enqueue: discrete or cast;
+//              tohc_enqueue_linearization: one k_fk and one k_broadphase_both for its two passes)
 //   per tail:  k_tail_pen -> k_tail_epa -> k_tail_range            (ONE launch each for all passes open at that time)
 //   per pass:  k_finish                                            (kernels and layouts: tohc_kernels.h)
 // Static obstacles are transformed once at upload (the reference re-syncs every object on every call,
