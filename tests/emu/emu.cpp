@@ -67,6 +67,7 @@ bool pairEval(World *w, const Cvx<1> &A, const Xf &tA, const Cvx<1> &B, const Xf
   }
   g_pre[pre]++;
   gjkMain<1>(A, B, tA, tB, md, st);
+  const int gjkIters = st.iters;   // (EMU_EPA_LOG)
   if (const char *lg = getenv("EMU_GJK_LOG")) {   // diagnostics: what a GJK run's length depends on (pairs the pre-test passes on)
     static FILE *f = fopen(lg, "w");
     V3 dir = tA.o - tB.o, ww;
@@ -108,7 +109,7 @@ bool pairEval(World *w, const Cvx<1> &A, const Xf &tA, const Cvx<1> &B, const Xf
       V3 dir = tA.o - tB.o, ww;
       float ov = 0;
       if (len2(dir) > 1e-12f) { dir = vdiv(dir, len(dir)); sepAxisBeyond<1>(A, B, tA, tB, dir, 0.f, ww); ov = -dot(dir, ww); }
-      if (es.epa_calls != prevCalls) fprintf(f, "%ld %d %d %d %d %g %g %d %d\n", es.epa_iters - prevIt, A.kind, A.n, B.kind, B.n, (double)st.distance, (double)ov, g_log_q, g_log_x), fflush(f);
+      if (es.epa_calls != prevCalls) fprintf(f, "%ld %d %d %d %d %g %g %d %d %ld %g %d\n", es.epa_iters - prevIt, A.kind, A.n, B.kind, B.n, (double)st.distance, (double)ov, g_log_q, g_log_x, es.last_g2, es.last_d0, gjkIters), fflush(f);
       prevIt = es.epa_iters; prevCalls = es.epa_calls;
     }
   }

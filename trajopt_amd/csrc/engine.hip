@@ -930,7 +930,9 @@ static int syncEngineImpl(tohc_engine *e) {
     overflow |= k.overflow != 0;
     for (int sh = 0; sh < TOHC_NSHARD; ++sh) {
       const CounterShard &cs = k.sh[sh];
-      overflow |= cs.n_pairs > segCap || cs.n_exact > segCap || cs.n_epa > segCap || cs.n_hits > segCap || cs.n_pen > segCap / TOHC_PEN_DIV;
+      // (n_pen may pass its shard's capacity without loss: k_tail_pen re-files such a pair under its block's shard and
+      // raises Counters::overflow itself when that one is full too)
+      overflow |= cs.n_pairs > segCap || cs.n_exact > segCap || cs.n_epa > segCap || cs.n_hits > segCap;
       np += cs.n_cand; ng += cs.n_pairs; ne += cs.n_epa;
       gi += cs.n_gjk_steps; ps += cs.n_pen_sups; es += cs.n_epa_sups; er += cs.n_epa_redone;
     }

@@ -1533,6 +1533,9 @@ struct TailArgs {
 #ifndef TOHC_PEN_WAVES
 #define TOHC_PEN_WAVES 2
 #endif
+#ifndef TOHC_PEN_CLASSES
+#define TOHC_PEN_CLASSES 1   // 0: a pair goes to the shard of its block, whatever its GJK2 took (A/B measurements)
+#endif
 // NH: heads in this launch (1: a constant index, the arguments stay where the launch put them); CAST: 0 / 1 = every
 // pair of the launch is discrete / cast (known at compile time when there is one head), 2 = ask the head
 template <int G, int NH, int CAST>
@@ -1569,14 +1572,35 @@ __global__ void __launch_bounds__(64, TOHC_PEN_WAVES) k_tail_pen(TailArgs ta) {
     const bool toEpa = G == 1 ? penInside<G, G2Mem>(&mem[threadIdx.x / G], A, B, lA, lB, g)
                               : penStage1<G, G2Mem>(&mem[threadIdx.x / G], A, B, lA, lB, g, isValid2, sep, tmpA, tmpB);
     const int shard = blockIdx.x % TOHC_NSHARD;
+    int pshard = shard;
     unsigned int slot = 0;
     bool writeP = toEpa;
-    if (G == 1) slot = waveSlot(&a.cnt->sh[shard].n_pen, toEpa);
+    if (G == 1 && TOHC_PEN_CLASSES) {
+      // k_tail_epa runs eight pairs of the queue in lock step, and a wavefront lasts as long as its longest run.  How long
+      // an EPA run gets shows in how soon this GJK2 enclosed the origin: <= 3 passes of its loop -> 9.8 EPA iterations on
+      // average (7 - 13), 4 -> 6.0, 5 -> 4.0, >= 6 -> 2.3 (config 4, host emulation; correlation -0.76).  The queue's
+      // shards are read one after the other, so filing a pair under its class -- four shards per class, the block number
+      // picks one -- puts like beside like, the long runs first: 14 % fewer lock-step iterations in the CPU model
+      // (scripts/epa_lockstep_model.py).  One atomic per class present in the wavefront.
+      const unsigned int cls = g.iters <= 3u ? 0u : g.iters == 4u ? 1u : g.iters == 5u ? 2u : 3u;
+      pshard = (int)(cls * (TOHC_NSHARD / 4) + (blockIdx.x & (TOHC_NSHARD / 4 - 1)));
+      unsigned long long todo = __ballot(toEpa);
+      while (todo) {
+        const int ps = __shfl(pshard, (int)__builtin_ctzll(todo));
+        const bool mine = toEpa && pshard == ps;
+        const unsigned int sl = waveSlot(&a.cnt->sh[ps].n_pen, mine);
+        if (mine) slot = sl;
+        todo &= ~__ballot(mine);
+      }
+      // (a class's four shards are full -- one class can hold most of the queue: the pair goes to its block's shard like
+      // any pair did before; a shard's count may then pass its capacity, readers stop at the capacity: qprefix)
+      if (toEpa && slot >= cap2) { pshard = shard; slot = atomicAdd(&a.cnt->sh[shard].n_pen, 1u); }
+    } else if (G == 1) slot = waveSlot(&a.cnt->sh[shard].n_pen, toEpa);
     else if (toEpa && Grp<G>::lane() == 0) slot = atomicAdd(&a.cnt->sh[shard].n_pen, 1u);
     else writeP = false;
     if (writeP) {
       if (slot < cap2) {
-        PenRec *r = &a.penq[(size_t)shard * cap2 + slot];
+        PenRec *r = &a.penq[(size_t)pshard * cap2 + slot];
         r->e = e;
         penSave<G, G2Mem>(r->h, g);
       } else {

@@ -1033,7 +1033,7 @@ TOHC_DEV float projOrigin4(V3 a, V3 b, V3 c, V3 d, float *w, unsigned &m) {  // 
 
 enum { G2_VALID, G2_INSIDE, G2_FAILED };
 #if defined(TOHC_EMU_STATS)
-struct EmuStats { long gjk2_calls, gjk2_iters, epa_calls, epa_iters, epa_faces, enclose_appends, hist_epa[72], status[12], inside, hist_g2[130]; };
+struct EmuStats { long gjk2_calls, gjk2_iters, epa_calls, epa_iters, epa_faces, enclose_appends, hist_epa[72], status[12], inside, hist_g2[130]; long last_g2; double last_d0; };
 inline EmuStats &emuStats() { static EmuStats s; return s; }
 #define TOHC_STAT(x) x
 #else
@@ -1050,6 +1050,7 @@ struct Gjk2 {
   unsigned nfree, current;
   int status;
   unsigned nsup = 0;   // support queries so far (work counter; not part of the algorithm)
+  unsigned iters = 0;  // passes of evaluate()'s loop (k_tail_pen files a pair by it: the fewer, the longer its EPA run)
 
   TOHC_DEV void support(V3 d, unsigned sv) {  // getsupport [epa:372-376]
     ++nsup;
@@ -1145,6 +1146,8 @@ struct Gjk2 {
       }
       status = ((++iterations) < 128) ? status : G2_FAILED;
     } while (status == G2_VALID);
+    iters = iterations;
+    TOHC_STAT(emuStats().last_g2 = (long)iterations;)
     TOHC_STAT(emuStats().gjk2_calls++; emuStats().gjk2_iters += iterations; emuStats().hist_g2[iterations < 129 ? iterations : 129]++; if (status == G2_INSIDE) emuStats().inside++;)
     switch (status) {
       case G2_VALID: distance = len(ray); break;
@@ -1541,6 +1544,7 @@ struct Epa {
       TOHC_PROF_ACC(prof, 5, tnf);
       if (hullCount == 4) {
         unsigned best = findbest();
+        TOHC_STAT(emuStats().last_d0 = (double)m->fnd[best][3];)
         V3 outerN = ld3(m->fnd[best]);
         float outerD = m->fnd[best][3];
         uint32_t ocp = m->fcp[best];
