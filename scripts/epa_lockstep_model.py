@@ -1,7 +1,7 @@
 """CPU model of k_tail_epa's lock step (no GPU): the EPA run lengths of config 4 from the host emulation (EMU_EPA_LOG: one
 line per run with its iteration count and the pair's child numbers), then what a wavefront of eight runs costs under
 different orders of the queue and under two-phase schemes.  A wavefront costs max(iterations of its 8 runs) + 2.5 (the
-shared prologue / epilogue, in iterations).
+shared prologue / epilogue, in iterations).  It is where filing the queue by the class of the pair's GJK2 came from.
 
   python scripts/epa_lockstep_model.py [problems]      (default 6; ~1 minute)
 """
@@ -48,7 +48,7 @@ allowed[c0["objA"], c0["objB"]] = 0
 allowed[c0["objB"], c0["objA"]] = 0
 w.set_allowed(allowed)
 
-rows = []   # problem, t, cast, iterations, query child, other child, distance
+rows = []   # problem, t, cast, iterations, query child, other child, distance, passes of Penetration's GJK2, GJK iterations
 for p in range(nP):
     traj = synth.fullbody_trajectory(rb, np.random.default_rng(1000 + p), 100)
     Ts = [poses(rb, q) for q in traj]
@@ -66,7 +66,7 @@ for p in range(nP):
                     f.seek(pos)
                     for line in f:
                         a = line.split()
-                        rows.append((p, t, cast, int(a[0]), int(a[7]), int(a[8]), float(a[5])))
+                        rows.append((p, t, cast, int(a[0]), int(a[7]), int(a[8]), float(a[5]), int(a[9]), int(a[11])))
 r = np.array(rows)
 rng = np.random.default_rng(0)
 
@@ -83,7 +83,13 @@ it = r[:, 3]
 bound = it.sum() / 8 + 2.5 * len(it) / 8
 print("%d EPA runs, %.2f iterations on average, at most %d; histogram %s" % (len(it), it.mean(), it.max(), np.bincount(it.astype(int)).tolist()))
 print("no-waste bound (every lane group busy all the time): %.0f" % bound)
+g2 = r[:, 7]
+cls = np.where(g2 <= 3, 0, np.where(g2 == 4, 1, np.where(g2 == 5, 2, 3)))   # k_tail_pen's classes
+print("passes of Penetration's GJK2 against the EPA run that follows: correlation %.2f; by class (<= 3, 4, 5, >= 6 passes): share %s, mean EPA iterations %s"
+      % (np.corrcoef(g2, it)[0, 1], [round(float((cls == c).mean()), 2) for c in range(4)], [round(float(it[cls == c].mean()), 1) if (cls == c).any() else None for c in range(4)]))
 orders = {"as queued (random)": rng.permutation(len(r)),
+          "FILED BY GJK2 CLASS (what k_tail_pen does)": np.lexsort((rng.uniform(size=len(r)), cls)),
+          "filed by the exact number of GJK2 passes": np.lexsort((rng.uniform(size=len(r)), g2)),
           "sorted by (query child, other child, problem, t)": np.lexsort((r[:, 1], r[:, 0], r[:, 5], r[:, 4])),
           "sorted by penetration depth": np.argsort(r[:, 6]),
           "sorted by run length (what no predictor can know)": np.argsort(it)}
