@@ -86,6 +86,9 @@ typedef struct tohc_counters {
   /* EPA runs that left the small first-attempt pools of k_tail_epa and were repeated on the reference's full pools
    * (64 support vertices, 128 faces): same results either way, this only says how often the short cut missed */
   int64_t epa_redone, cum_epa_redone;
+  /* penetration pairs whose class shard of the k_tail_pen -> k_tail_epa queue was full and that went to their block's
+   * shard instead (the queue is filed by how long the pair's EPA run is expected to be; same results either way) */
+  int64_t pen_refiled, cum_pen_refiled;
 } tohc_counters;
 
 /* replaces CreateCollisionChecker(env)                       src/trajopt/bullet_collision_checker.cpp:1036-1039 */

@@ -24,7 +24,10 @@ VARIANTS = [{}, {"TOHC_PRETEST": "0"}, {"TOHC_STREAMS": "1"}, {"TOHC_CHUNKS": "2
             {"TOHC_EPA_SMALL": "5,10"},   # EPA's first-attempt pools so small that most runs are repeated on the full pools
             {"TOHC_DEFER_EXACT": "0"},    # the exact stage of the pre-test inside k_broadphase instead of in k_exact
             {"TOHC_GJK_SPLIT": "0"},      # every GJK run ends where it started (k_gjk) ...
-            {"TOHC_GJK_SPLIT": "1"}]      # ... or nearly every one goes on in k_gjk_cont (default: after 6 passes)
+            {"TOHC_GJK_SPLIT": "1"},      # ... or nearly every one goes on in k_gjk_cont (default: after 6 passes)
+            {"TOHC_PEN_CAP": "700"},      # shards of the penetration hand-over queue so small that the largest class of pairs overflows
+                                          # its four and falls back to the blocks' shards (k_tail_pen files pairs by GJK2 class)
+            {"TOHC_GJK_ADAPT": "0"}, {"TOHC_HEADS_FIRST": "0"}]
 
 
 def _world():
@@ -93,6 +96,8 @@ def test_engine_variants_compute_the_same_slab(built):
             assert c["gjk_evals"] == c["pair_evals"]
         if "TOHC_DEFER_EXACT" in env:   # the same test in either place: the same pairs reach k_gjk
             assert c["gjk_evals"] == ref_c["gjk_evals"], tag
+        if "TOHC_PEN_CAP" in env:
+            assert c["pen_refiled"] > 0 and ref_c["pen_refiled"] == 0, (c["pen_refiled"], ref_c["pen_refiled"])
         if "TOHC_EPA_SMALL" in env:
             assert c["epa_redone"] > 0.05 * c["epa_evals"] > 0, (c["epa_redone"], c["epa_evals"])
     # and the slab is right: one problem against the oracle, pass by pass

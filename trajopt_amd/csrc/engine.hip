@@ -158,6 +158,8 @@ struct tohc_engine {
   // pass).  The host needs ~0.1 ms to submit one pass's ten launches and event operations; for a single problem, whose
   // kernels last 10 - 100 us each, the second pass's head otherwise starts that much later than it could.
   int heads_first = 1;
+  unsigned int pen_cap_limit = ~0u;   // TOHC_PEN_CAP=n: a shard of the penetration hand-over queue takes n pairs at most (tests of
+                                      // k_tail_pen's fall-back from a full class shard to the block's shard)
   hipStream_t tail_stream = nullptr;
   hipEvent_t tail_ranged = nullptr;  // recorded after the latest k_tail_range
   bool have_ranged = false;
@@ -374,6 +376,7 @@ int tohc_create(tohc_engine **out, int device) {
   }
   if (const char *mt = getenv("TOHC_MERGE_TAIL")) e->max_open = atoi(mt) != 0 ? TOHC_MAX_HEADS : 1;
   if (const char *hf = getenv("TOHC_HEADS_FIRST")) e->heads_first = atoi(hf) != 0;
+  if (const char *pc = getenv("TOHC_PEN_CAP")) e->pen_cap_limit = (unsigned int)std::max(atoi(pc), 1);
   if (const char *eb = getenv("TOHC_EPA_BLOCK")) e->epa_block = atoi(eb) == 16 ? 16 : 64;
   if (const char *ub = getenv("TOHC_UNIT_BP")) e->unit_broadphase = std::max(atoi(ub), 0);
   if (const char *tm = getenv("TOHC_TIMING")) e->timing = atoi(tm) != 0;
@@ -920,13 +923,13 @@ static int syncEngineImpl(tohc_engine *e) {
   unsigned int worst_pairs = 0;
   tohc_counters &c = e->counters;
   c.aabb_tests = c.pair_evals = c.epa_evals = c.gjk_evals = 0;
-  c.gjk_iters = c.pen_supports = c.epa_supports = c.epa_redone = 0;
+  c.gjk_iters = c.pen_supports = c.epa_supports = c.epa_redone = c.pen_refiled = 0;
   c.ms_last_call = 0;
   for (const auto &pd : e->pending) {
     const Counters &k = e->h_cnt.p[1 + pd.slot];
     const unsigned int segCap = (unsigned int)(e->max_pairs / TOHC_NSHARD);
     unsigned int np = 0, ne = 0, ng = 0;
-    int64_t gi = 0, ps = 0, es = 0, er = 0;
+    int64_t gi = 0, ps = 0, es = 0, er = 0, pr = 0;
     overflow |= k.overflow != 0;
     for (int sh = 0; sh < TOHC_NSHARD; ++sh) {
       const CounterShard &cs = k.sh[sh];
@@ -934,11 +937,12 @@ static int syncEngineImpl(tohc_engine *e) {
       // raises Counters::overflow itself when that one is full too)
       overflow |= cs.n_pairs > segCap || cs.n_exact > segCap || cs.n_epa > segCap || cs.n_hits > segCap;
       np += cs.n_cand; ng += cs.n_pairs; ne += cs.n_epa;
-      gi += cs.n_gjk_steps; ps += cs.n_pen_sups; es += cs.n_epa_sups; er += cs.n_epa_redone;
+      gi += cs.n_gjk_steps; ps += cs.n_pen_sups; es += cs.n_epa_sups; er += cs.n_epa_redone; pr += cs.n_pen_refiled;
     }
     c.gjk_iters += gi; c.pen_supports += ps; c.epa_supports += es;
     c.cum_gjk_iters += gi; c.cum_pen_supports += ps; c.cum_epa_supports += es;
     c.epa_redone += er; c.cum_epa_redone += er;
+    c.pen_refiled += pr; c.cum_pen_refiled += pr;
     worst_pairs = std::max(worst_pairs, ng);
     if (pd.kind >= 0) { e->gjk_hint[pd.kind].units = pd.units; e->gjk_hint[pd.kind].pairs = ng; }
     c.aabb_tests += pd.aabb_tests; c.pair_evals += np; c.epa_evals += ne; c.gjk_evals += ng;
@@ -1165,6 +1169,7 @@ static int narrowPrepare(tohc_engine *e, const DynMap &dm, const int *d_qchildre
   if (cp.t_disc <= 0) cp.t_disc = cp.T;   // (no window: the discrete pass covers every staged timestep)
   const size_t qcap = (size_t)cp.seg_cap * TOHC_NSHARD;
   HIPCHK(ln.pairs.reserve(qcap)); HIPCHK(ln.epaq.reserve(qcap)); HIPCHK(ln.hits.reserve(qcap));
+  cp.pen_cap = std::min(cp.seg_cap / TOHC_PEN_DIV, e->pen_cap_limit);
   HIPCHK(ln.penq.reserve((size_t)(cp.seg_cap / TOHC_PEN_DIV) * TOHC_NSHARD));
   HIPCHK(ln.distq.reserve(qcap));
   {

@@ -115,7 +115,8 @@ struct CounterShard {
   unsigned int n_epa_redone;  // EPA runs repeated on the full pools
   unsigned int n_exact;       // pairs k_broadphase's sphere stage leaves for k_exact (NarrowArgs.cands)
   unsigned int n_cont;        // GJK runs k_gjk hands to k_gjk_cont (NarrowArgs.contq)
-  unsigned int pad[21];
+  unsigned int n_pen_refiled; // pairs k_tail_pen filed under their block's shard because their class's shards were full
+  unsigned int pad[20];
 };
 struct Counters {
   CounterShard sh[TOHC_NSHARD];
@@ -136,6 +137,7 @@ struct CallParams {
   float d, breaking;
   unsigned int seg_cap;      // capacity of ONE shard of the pair / EPA / hit queues
   unsigned int max_records;
+  unsigned int pen_cap;      // capacity of ONE shard of the k_tail_pen -> k_tail_epa queue: seg_cap / TOHC_PEN_DIV (less only in tests: TOHC_PEN_CAP)
   int dbg_max_iter;          // diagnostics only: 1000 = the reference's gGjkMaxIter
   int ordered_pairs;         // AllVsAll: a query child meets only the children of objects with a higher number
   unsigned int epa_small_v, epa_small_f;   // k_tail_epa's first-attempt pools (<= TOHC_EPA_SMALL_V / _F; smaller only in tests)
@@ -1552,7 +1554,7 @@ __global__ void __launch_bounds__(64, TOHC_PEN_WAVES) k_tail_pen(TailArgs ta) {
   const unsigned int nepa = pre.start[TOHC_NSHARD];
   float md2 = a.cp.breaking;
   md2 *= md2;
-  const unsigned int cap2 = a.cp.seg_cap / TOHC_PEN_DIV;
+  const unsigned int cap2 = a.cp.pen_cap;
   unsigned int sups = 0;
   for (unsigned int i = gid; i < nepa; i += nlanes) {
     const unsigned int qpos = qlocate(pre, a.cp.seg_cap, i);
@@ -1593,8 +1595,15 @@ __global__ void __launch_bounds__(64, TOHC_PEN_WAVES) k_tail_pen(TailArgs ta) {
         todo &= ~__ballot(mine);
       }
       // (a class's four shards are full -- one class can hold most of the queue: the pair goes to its block's shard like
-      // any pair did before; a shard's count may then pass its capacity, readers stop at the capacity: qprefix)
-      if (toEpa && slot >= cap2) { pshard = shard; slot = atomicAdd(&a.cnt->sh[shard].n_pen, 1u); }
+      // any pair did before, or to the next one with room; a shard's count may then pass its capacity, readers stop at
+      // the capacity: qprefix)
+      if (toEpa && slot >= cap2) {
+        atomicAdd(&a.cnt->sh[shard].n_pen_refiled, 1u);
+        for (int k = 0; k < TOHC_NSHARD && slot >= cap2; ++k) {   // the block's own shard first, then whichever still has room
+          pshard = (shard + k) % TOHC_NSHARD;
+          slot = atomicAdd(&a.cnt->sh[pshard].n_pen, 1u);
+        }
+      }
     } else if (G == 1) slot = waveSlot(&a.cnt->sh[shard].n_pen, toEpa);
     else if (toEpa && Grp<G>::lane() == 0) slot = atomicAdd(&a.cnt->sh[shard].n_pen, 1u);
     else writeP = false;
@@ -1673,7 +1682,7 @@ __global__ void __launch_bounds__(BLOCK, TOHC_EPA_WAVES) k_tail_epa(TailArgs ta)
   for (int hh = 0; hh < NH; ++hh) {   // the block's own head first, then whatever the others still hold
     const int head = NH == 1 ? 0 : (int)((blockIdx.x + (unsigned int)hh) % (unsigned int)NH);
     const NarrowArgs &a = ta.h[head];
-    const unsigned int cap2 = a.cp.seg_cap / TOHC_PEN_DIV;
+    const unsigned int cap2 = a.cp.pen_cap;
     QPrefix pre;
     qprefix(&a.cnt->sh[0].n_pen, cap2, pre);
     const unsigned int npen = pre.start[TOHC_NSHARD];

@@ -27,7 +27,8 @@ class Counters(C.Structure):
                 ("gjk_evals", C.c_int64), ("cum_gjk_evals", C.c_int64), ("cum_ms_finish", C.c_double),
                 ("gjk_iters", C.c_int64), ("pen_supports", C.c_int64), ("epa_supports", C.c_int64),
                 ("cum_gjk_iters", C.c_int64), ("cum_pen_supports", C.c_int64), ("cum_epa_supports", C.c_int64),
-                ("epa_redone", C.c_int64), ("cum_epa_redone", C.c_int64)]
+                ("epa_redone", C.c_int64), ("cum_epa_redone", C.c_int64),
+                ("pen_refiled", C.c_int64), ("cum_pen_refiled", C.c_int64)]
 
 
 class Hinges(C.Structure):   # tohc_hinges
