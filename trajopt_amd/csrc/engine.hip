@@ -959,6 +959,20 @@ static int syncEngineImpl(tohc_engine *e) {
     c.ms_last_call = std::max(c.ms_last_call, (double)span);
     c.cum_launches += 1;
   }
+#if defined(TOHC_EPA_TIMELINE)
+  if (e->d_dbg.p) {
+    unsigned long long h[256];
+    HIPCHK(hipMemcpy(h, e->d_dbg.p, sizeof h, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(e->d_dbg.p, 0, sizeof h));
+    fprintf(stderr, "[epa timeline] wavefront lifetimes, 25 us bins:");
+    for (int k = 0; k < 32; ++k) fprintf(stderr, " %llu", h[160 + k]);
+    fprintf(stderr, "\n[epa timeline] round durations, 10 us bins:");
+    for (int k = 0; k < 32; ++k) fprintf(stderr, " %llu", h[192 + k]);
+    fprintf(stderr, "\n[epa timeline] us spent in rounds by when they began in their wavefront's life, 25 us bins:");
+    for (int k = 0; k < 32; ++k) fprintf(stderr, " %llu", h[224 + k] / 100ull);
+    fprintf(stderr, "\n");
+  }
+#endif
 #if defined(TOHC_EPA_PROF)
   if (e->d_dbg.p) {
     unsigned long long h[160];
@@ -1179,8 +1193,8 @@ static int narrowPrepare(tohc_engine *e, const DynMap &dm, const int *d_qchildre
   cp.gjk_split = (e->gjk_group == 1 && !L.gjk16) ? e->gjk_split : 0;
   if (cp.gjk_split > 0) HIPCHK(ln.contq.reserve((size_t)(cp.seg_cap / TOHC_CONT_DIV) * TOHC_NSHARD));
   if (e->defer_exact) HIPCHK(ln.cands.reserve(qcap));
-#if defined(TOHC_EPA_PROF)
-  if (!e->d_dbg.p) { HIPCHK(e->d_dbg.reserve(160)); HIPCHK(hipMemset(e->d_dbg.p, 0, 160 * sizeof(unsigned long long))); }
+#if defined(TOHC_EPA_PROF) || defined(TOHC_EPA_TIMELINE)
+  if (!e->d_dbg.p) { HIPCHK(e->d_dbg.reserve(256)); HIPCHK(hipMemset(e->d_dbg.p, 0, 256 * sizeof(unsigned long long))); }
 #endif
   HIPCHK(e->d_records.reserve(e->max_records));
   HIPCHK(e->d_grads.reserve(e->max_records * 2 * (size_t)K));

@@ -1679,6 +1679,9 @@ __global__ void __launch_bounds__(BLOCK, TOHC_EPA_WAVES) k_tail_epa(TailArgs ta)
   EpaMemS *ms = reinterpret_cast<EpaMemS *>(lds) + threadIdx.x / G;
   EpaMem *mb = reinterpret_cast<EpaMem *>(lds);
   unsigned int sups = 0, redone = 0;
+#if defined(TOHC_EPA_TIMELINE)   // diagnostics build: how long the wavefronts of this kernel live and how long their rounds last
+  const unsigned long long tl_start = wall_clock64();   // (100 MHz)
+#endif
   for (int hh = 0; hh < NH; ++hh) {   // the block's own head first, then whatever the others still hold
     const int head = NH == 1 ? 0 : (int)((blockIdx.x + (unsigned int)hh) % (unsigned int)NH);
     const NarrowArgs &a = ta.h[head];
@@ -1693,6 +1696,9 @@ __global__ void __launch_bounds__(BLOCK, TOHC_EPA_WAVES) k_tail_epa(TailArgs ta)
       if (threadIdx.x == 0) first = atomicAdd(&a.cnt->epa_next, (unsigned int)groupsPerBlock);
       first = __shfl(first, 0);
       if (first >= npen) break;
+#if defined(TOHC_EPA_TIMELINE)
+      const unsigned long long tl_r0 = wall_clock64();
+#endif
       const unsigned int i = first + threadIdx.x / G;
       const bool mine = i < npen;
       const PenRec *r = &a.penq[qlocate(pre, cap2, mine ? i : first)];
@@ -1748,8 +1754,22 @@ __global__ void __launch_bounds__(BLOCK, TOHC_EPA_WAVES) k_tail_epa(TailArgs ta)
         pushIfContact<G>(a, (unsigned int)e.pair, st, md2);
         if (Grp<G>::lane() == 0) sups += nsup;
       }
+#if defined(TOHC_EPA_TIMELINE)
+      if (threadIdx.x == 0 && a.dbg) {
+        const unsigned long long dur = (wall_clock64() - tl_r0) / 1000ull;            // 10 us bins
+        atomicAdd(&a.dbg[192 + (dur < 31 ? dur : 31)], 1ull);
+        const unsigned long long at = (tl_r0 - tl_start) / 2500ull;                   // when the round began in the wavefront's life, 25 us bins
+        atomicAdd(&a.dbg[224 + (at < 31 ? at : 31)], wall_clock64() - tl_r0);         // time spent in rounds begun in that bin
+      }
+#endif
     }
   }
+#if defined(TOHC_EPA_TIMELINE)
+  if (threadIdx.x == 0 && ta.h[0].dbg) {
+    const unsigned long long life = (wall_clock64() - tl_start) / 2500ull;            // 25 us bins
+    atomicAdd(&ta.h[0].dbg[160 + (life < 31 ? life : 31)], 1ull);
+  }
+#endif
   // (work counters only: booked on the block's own head)
   CounterShard *cs = &ta.h[NH == 1 ? 0 : blockIdx.x % (unsigned int)NH].cnt->sh[blockIdx.x % TOHC_NSHARD];
   if (Grp<G>::lane() != 0) redone = 0;
