@@ -108,3 +108,38 @@ for N in (6, 7, 8, 10):
 key = {(a[0], a[2], a[4], a[5], a[1]): a[3] for a in r}
 pairs = [(v, key[(p, c, q, x, t + 1)]) for (p, c, q, x, t), v in key.items() if (p, c, q, x, t + 1) in key]
 print("the same pair at t and t + 1: %d cases, correlation of run lengths %.2f" % (len(pairs), np.corrcoef(np.array(pairs).T)[0, 1]))
+
+
+def refill_cost(itq, m, c0=2.5, G=8):
+    """Lane groups that take their next run themselves: a refill (epilogue of the finished runs + prologue of the next:
+    c0 iterations of wavefront time, the running groups masked off meanwhile) happens as soon as m groups are idle -- or
+    all that are left; m = G is the lock step of today's rounds."""
+    q = list(itq)
+    qi = 0
+    rem = np.zeros(G)
+    t = 0.0
+    while True:
+        idle = int((rem <= 0).sum())
+        if qi < len(q) and (idle >= m or idle == G):
+            for g in range(G):
+                if rem[g] <= 0 and qi < len(q):
+                    rem[g] = q[qi]; qi += 1
+            t += c0
+            continue
+        if idle == G:
+            break
+        if qi >= len(q):          # nothing left to hand out: run the rest down
+            t += rem.max(); break
+        step = np.sort(rem[rem > 0])[max(0, m - idle - 1)] if idle < m else 1   # until enough groups are idle
+        rem = rem - step
+        t += step
+    return t
+
+
+W = 2048 * 0 + 256   # wavefronts that share the queue in the model (each takes its runs in queue order, round robin)
+for name in ("as queued (random)", "FILED BY GJK2 CLASS (what k_tail_pen does)"):
+    o = orders[name]
+    seq = it[o]
+    for m in (8, 6, 4, 3, 2, 1):
+        tot = sum(refill_cost(seq[wv::W], m) for wv in range(W))
+        print("  self-refilling lane groups, refill when %d idle, %-44s %.0f = %.2f x bound" % (m, name + ":", tot, tot / bound))
