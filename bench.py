@@ -517,7 +517,7 @@ def main():
         assert len(counts) == world and counts[rank] == len(rec)
 
     # host-delivered rate on rank 0's data (never `value`)
-    api = lat_ms = lat_dev_ms = sweep_ms = n_sw = None
+    api = lat_ms = lat_dev_ms = sweep_ms = n_sw = quiet = None
     hinge = None
     if rank == 0 and not args.hot_path_only:
         # The same workload delivered as what the SQP host feeds its QP solver: hinge rows + BPMPD columns
@@ -565,6 +565,21 @@ def main():
         api = pe / (time.perf_counter() - ta)
         # latency of ONE problem's linearization, results in host memory (north-star: < 1 ms)
         lat_ms, lat_dev_ms = single_problem_latency(eng, dofs, T)
+        # the timed step once more with the per-stage timing events off (what a production caller sets; `value` keeps them on,
+        # kernel_ms_per_pass and the roofline are read from them)
+        eng.stage_dofs(dofs, P, T)
+        eng.set_kernel_timing(False)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        pe0, tq0, nq_ = eng.counters()["cum_pair_evals"], time.perf_counter(), 0
+        while time.perf_counter() - tq0 < 1.0:
+            step(); nq_ += 1
+        torch.cuda.synchronize()
+        quiet_dt = time.perf_counter() - tq0
+        quiet = {"value": (eng.counters()["cum_pair_evals"] - pe0) / quiet_dt, "ms_per_step": quiet_dt / nq_ * 1e3, "steps": nq_,
+                 "what": "the same step with tohc_set_kernel_timing(0): no HIP events between the kernels (never `value`)"}
+        eng.set_kernel_timing(True)
         # ContinuousCheckTrajectory (the acceptance check of the reference's tests) of one problem, hits in host memory
         sw = []
         for _ in range(5):
@@ -637,6 +652,7 @@ def main():
             "config": {"workload": workload_text(args.config, P, T, rb.K), "problems_per_gpu": P, "timesteps": T, "K": rb.K,
                        "parallelism": "problems sharded over %d GPU(s), no collective" % world},
             "value_scope": "device slab complete (tohc_sync); no D2H, no canonical order -- see value_host_delivered",
+            "value_kernel_timing_off": quiet,
             "value_host_delivered": api,
             "value_host_delivered_scope": "stage + enqueue + tohc_fetch: every contact record (152 B) + 2K gradient doubles in canonical order in pinned host memory, one linearization at a time",
             "value_host_delivered_hinges": hinge,
