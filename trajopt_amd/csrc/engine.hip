@@ -1043,6 +1043,9 @@ static int64_t countAabbTests(const tohc_engine *e, const std::vector<int> &qchi
 #ifndef TOHC_FINISH_G
 #define TOHC_FINISH_G 4   // lanes per hit in k_finish: most of a hit's work is the same for every lane of its group (measured per launch: 16 lanes 0.38 ms, 8: 0.29, 4: 0.22, 2: 0.23, 1: 0.20 but 73 KB of LDS rows per block at K = 18)
 #endif
+#ifndef TOHC_FINISH_BLOCKS_PER_CU_DISCRETE
+#define TOHC_FINISH_BLOCKS_PER_CU_DISCRETE 4   // the discrete pass's kernel: ~108 VGPRs, four waves per SIMD
+#endif
 #ifndef TOHC_FINISH_BLOCKS_PER_CU
 #define TOHC_FINISH_BLOCKS_PER_CU 2   // with TOHC_FINISH_WAVES 2: two waves per SIMD = 2 blocks of 256 per CU, the whole grid resident at once (measured step: 1 block 2.41 ms, 2: 2.31, 3: 2.35, 4: 2.34, 8: 2.32)
 #endif
@@ -1114,8 +1117,15 @@ static int launchTail(tohc_engine *e) {
       // LDS: one pair of gradient rows per group -- only the lane-per-joint epilogue (fast_jac: K <= TOHC_FAST_JAC_MAXK, so at
       // most 64 KB for groups of 4) touches them; the lane-per-column fall-back (wide K, mimic joints) asks for none
       const size_t Kr = h.a.rb.fast_jac ? (size_t)std::max(h.a.rb.K, 1) : 0;
-      if (e->group == 64) hipLaunchKernelGGL((k_finish<64>), dim3(256 * 2), dim3(256), (size_t)(256 / 64) * 2 * Kr * sizeof(double), ln.stream, h.a);
-      else hipLaunchKernelGGL((k_finish<TOHC_FINISH_G>), dim3(256 * TOHC_FINISH_BLOCKS_PER_CU), dim3(256), (size_t)(256 / TOHC_FINISH_G) * 2 * Kr * sizeof(double), ln.stream, h.a);
+      const bool castPass = h.a.cp.cast != 0;
+      if (e->group == 64) {
+        if (castPass) hipLaunchKernelGGL((k_finish<64, true>), dim3(256 * 2), dim3(256), (size_t)(256 / 64) * 2 * Kr * sizeof(double), ln.stream, h.a);
+        else hipLaunchKernelGGL((k_finish<64, false>), dim3(256 * 2), dim3(256), (size_t)(256 / 64) * 2 * Kr * sizeof(double), ln.stream, h.a);
+      } else if (castPass) {
+        hipLaunchKernelGGL((k_finish<TOHC_FINISH_G, true>), dim3(256 * TOHC_FINISH_BLOCKS_PER_CU), dim3(256), (size_t)(256 / TOHC_FINISH_G) * 2 * Kr * sizeof(double), ln.stream, h.a);
+      } else {
+        hipLaunchKernelGGL((k_finish<TOHC_FINISH_G, false>), dim3(256 * TOHC_FINISH_BLOCKS_PER_CU_DISCRETE), dim3(256), (size_t)(256 / TOHC_FINISH_G) * 2 * Kr * sizeof(double), ln.stream, h.a);
+      }
     }
     HIPCHK(recEv(e, ev, 8, ln.stream));
     HIPCHK(hipEventRecord(ln.done, ln.stream));

@@ -1896,11 +1896,16 @@ __device__ __forceinline__ double linearizeFast(const NarrowArgs &a, int set, in
 
 // k_finish: btBridgedManifoldResult::addContactPoint (btCollisionWorld.cpp:1068-1086), CastCollisionCollector
 // (bullet_collision_checker.cpp:894-972), record + gradient rows.
-template <int G>
+// CAST: the pass is a cast pass (a.cp.cast) -- a kernel of its own, so that the discrete pass's carries neither the
+// classification's code nor its registers (the query hull's vertices at two poses).
 #ifndef TOHC_FINISH_WAVES
 #define TOHC_FINISH_WAVES 2   // no spills (4: 128 VGPRs, 73 spilled; measured 2: 0.205, 3: 0.26, 4: 0.22, 5: 0.31 ms per launch)
 #endif
-__global__ void __launch_bounds__(256, TOHC_FINISH_WAVES) k_finish(NarrowArgs a) {
+#ifndef TOHC_FINISH_WAVES_DISCRETE
+#define TOHC_FINISH_WAVES_DISCRETE 4   // 104 VGPRs, no spills: four waves per SIMD (k_finish per pass, config 4: 0.230 -> 0.198 ms on average over the two passes)
+#endif
+template <int G, bool CAST>
+__global__ void __launch_bounds__(256, CAST ? TOHC_FINISH_WAVES : TOHC_FINISH_WAVES_DISCRETE) k_finish(NarrowArgs a) {
   extern __shared__ double s_rows[];   // [256 / G][2][K]: the groups' gradient rows (launch: finishLds)
   double *row = s_rows + (size_t)(threadIdx.x / G) * 2 * a.rb.K;
   const bool fast = a.rb.fast_jac != 0;
@@ -1939,7 +1944,7 @@ __global__ void __launch_bounds__(256, TOHC_FINISH_WAVES) k_finish(NarrowArgs a)
     int cctype = TOHC_CC_NONE;
     float time = 0;
     V3 ptB1 = mk(0, 0, 0);
-    if (a.cp.cast) {
+    if (CAST) {
       const bool castFirst = !c.xIsA;
       Cvx<G> cq;
       cvxLoad<G>(cq, dq.kind, mk(dq.dims[0], dq.dims[1], dq.dims[2]), a.sc.vx, a.sc.vy, a.sc.vz, a.sc.v4, dq.voff, dq.vcnt, a.sc.v8, dq.voff8);
@@ -1967,7 +1972,7 @@ __global__ void __launch_bounds__(256, TOHC_FINISH_WAVES) k_finish(NarrowArgs a)
       double *g = a.grads + (size_t)slot * 2 * a.rb.K;
       c0 = fast ? linearizeFast<G>(a, c.set0, jA, jB, n, pA, pB, (double)h.distance, g, row)
                 : linearizeAt<G>(a, c.set0, la, lb, n, pA, pB, (double)h.distance, g);
-      if (a.cp.cast) {
+      if (CAST) {
         const D3 pBc = (cctype == TOHC_CC_BETWEEN) ? pB1 : pB;
         c1 = fast ? linearizeFast<G>(a, c.set1, jA, jB, n, pA, pBc, (double)h.distance, g + a.rb.K, row)
                   : linearizeAt<G>(a, c.set1, la, lb, n, pA, pBc, (double)h.distance, g + a.rb.K);
