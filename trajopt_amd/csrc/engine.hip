@@ -1088,7 +1088,8 @@ static int launchTail(tohc_engine *e) {
       const unsigned int nd = ta.n_dist_blocks;
       if (e->group == 64) hipLaunchKernelGGL((k_tail_epa<64, 64, 1>), dim3(gridN + nd), dim3(64), 0, ts, ta);
       else if (e->epa_block == 16) hipLaunchKernelGGL((k_tail_epa<16, 16, 1>), dim3(gridN * 4 + nd), dim3(16), 0, ts, ta);  // one group per wavefront
-      else hipLaunchKernelGGL((k_tail_epa<TOHC_EPA_G, 64, 1>), dim3(TOHC_EPA_GRID + nd), dim3(64), 0, ts, ta);
+      else if (cast) hipLaunchKernelGGL((k_tail_epa<TOHC_EPA_G, 64, 1, 1>), dim3(TOHC_EPA_GRID + nd), dim3(64), 0, ts, ta);
+      else hipLaunchKernelGGL((k_tail_epa<TOHC_EPA_G, 64, 1, 0>), dim3(TOHC_EPA_GRID + nd), dim3(64), 0, ts, ta);
     } else {   // nh == TOHC_MAX_HEADS == 2
       if (e->pen_group == 4) hipLaunchKernelGGL((k_tail_pen<4, 2, 2>), dim3(gridN * 2), dim3(64), 0, ts, ta);
       else hipLaunchKernelGGL((k_tail_pen<1, 2, 2>), dim3(gridN * 2), dim3(64), 0, ts, ta);

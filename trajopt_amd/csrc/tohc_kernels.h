@@ -1637,7 +1637,8 @@ __global__ void __launch_bounds__(64, TOHC_PEN_WAVES) k_tail_pen(TailArgs ta) {
 // occupancy the registers allow); a run that would leave them is repeated from the hand-over on the reference's full
 // pools, which lie over the block's small ones -- the groups of the wavefront that need it take turns once all small
 // runs of the round have ended.
-template <int G, int BLOCK, int NH>
+// CAST: as in k_tail_pen (0 / 1: every pair of the launch is discrete / cast, 2: ask the head)
+template <int G, int BLOCK, int NH, int CAST = 2>
 __global__ void __launch_bounds__(BLOCK, TOHC_EPA_WAVES) k_tail_epa(TailArgs ta) {
   static_assert(BLOCK <= 64, "the groups of a block take turns on one full pool: one wavefront per block");
   constexpr int groupsPerBlock = BLOCK / G;
@@ -1659,7 +1660,7 @@ __global__ void __launch_bounds__(BLOCK, TOHC_EPA_WAVES) k_tail_epa(TailArgs ta)
         Cvx<1> A, B;
         Xf tA, tB, lA, lB;
         GjkState st;
-        loadQueued<1>(a, e, a.cp.cast != 0, A, B, tA, tB, st);
+        loadQueued<1>(a, e, CAST == 2 ? a.cp.cast != 0 : CAST == 1, A, B, tA, tB, st);
         const float md2 = pairMaxDist2<1>(A, B, a.cp.breaking);
         penLocal(tA, tB, st.offset, lA, lB);
         V3 tmpA = mk(0, 0, 0), tmpB = mk(0, 0, 0), sep = mk(0, 0, 0);
@@ -1706,7 +1707,7 @@ __global__ void __launch_bounds__(BLOCK, TOHC_EPA_WAVES) k_tail_epa(TailArgs ta)
       Cvx<G> A, B;
       Xf tA, tB, lA, lB;
       GjkState st;
-      loadQueued<G>(a, e, a.cp.cast != 0, A, B, tA, tB, st);
+      loadQueued<G>(a, e, CAST == 2 ? a.cp.cast != 0 : CAST == 1, A, B, tA, tB, st);
       const float md2 = pairMaxDist2<G>(A, B, a.cp.breaking);
       penLocal(tA, tB, st.offset, lA, lB);
       V3 tmpA = mk(0, 0, 0), tmpB = mk(0, 0, 0), sep = mk(0, 0, 0);
